@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the batched CartPole VecEnv step on MI355X (BASELINE.json metric).
+
+Workload (config.workload): BASELINE.json configs[4] CartPole leg — 16,777,216 envs per GPU, TimeLimit(500)+Monitor,
+fused step + in-kernel auto-reset, one `VecEnv::step` == one kernel launch, LOCKSTEP (fp64-state) arithmetic, i.e. the
+kernel whose streams are bit-exact against the CPU oracle (tests/test_gpu_classic_lockstep.py).  configs[1] (N=65,536)
+is the parity-test case: at 6.5 MB per step it is launch-latency-bound and cannot show a roofline fraction.
+Envs shard across GPUs with no data-path collective (weak scaling: per-GPU work fixed).
+
+One JSON line on stdout (rank 0).  `value` counts env-steps of ALL ranks / max-over-ranks wall time, inputs resident
+in HBM.  `roofline` prices the step kernel: algorithmic bytes per env-step x envs per launch / mean launch duration
+(HIP events on the launch stream).  `cpu_baseline` is the CPU oracle (a port of the reference's per-env-object
+SyncVecEnv loop) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+# Algorithmic HBM bytes per env-step: state read+write, obs write, action, reward, done, step counter r/w
+BYTES_PER_STEP = {
+    ("cartpole", "lockstep"): 32 + 32 + 16 + 4 + 4 + 4 + 8,   # 100
+    ("cartpole", "f32"): 16 + 16 + 4 + 4 + 4 + 8,             # 52 (obs aliases the state)
+    ("mountaincar", "lockstep"): 16 + 16 + 8 + 4 + 4 + 4 + 8,  # 60
+    ("mountaincar", "f32"): 8 + 8 + 4 + 4 + 4 + 8,             # 36
+}
+
+
+def time_engine(torch, dist, eng, actions, steps, warmup, world):
+    """W untimed + K timed VecEnv steps.  Returns (wall seconds max over ranks, mean kernel ms from HIP events)."""
+    for w in range(warmup):
+        eng.step(actions[w % len(actions)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record()
+        eng.step(actions[k % len(actions)])
+        ev[k][1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    return dt, kern_ms
+
+
+def cpu_baseline(n_envs, seconds_target):
+    """CPU oracle (port of the reference's SyncVecEnv loop over per-env wrapper objects), bounded sample."""
+    import numpy as np
+    from tests.oracle_lib import CARTPOLE, F_MONITOR, F_TIME_LIMIT, Oracle, default_threads, splitmix_actions
+    o = Oracle()
+    out = {}
+    for label, threads in (("1", 1), ("all", default_threads())):
+        ov = o.vec(CARTPOLE, n_envs, F_TIME_LIMIT | F_MONITOR, 500, threads=threads)
+        ov.seed(0)
+        ov.reset()
+        T = 250
+        acts = splitmix_actions(99, T, n_envs, 2)
+        done_steps, secs = 0, 0.0
+        while secs < seconds_target:
+            r = ov.rollout(acts, rec_reward=False, rec_done=False, rec_trunc=False)
+            secs += r["seconds"]
+            done_steps += T * n_envs
+        out[label] = (done_steps / secs, threads, done_steps, secs)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=16 * 1024 * 1024)
+    ap.add_argument("--env", default="cartpole", choices=["cartpole", "mountaincar"])
+    ap.add_argument("--mode", default="lockstep", choices=["lockstep", "f32"])
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (f32 / MountainCar) measurements")
+    args = ap.parse_args()
+
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    n = args.envs_per_gpu
+
+    def build(env, mode):
+        kind = L.ENV_CARTPOLE if env == "cartpole" else L.ENV_MOUNTAINCAR
+        wrappers = L.WRAP_TIME_LIMIT | L.WRAP_MONITOR | (L.WRAP_CLIP_REWARD if env == "mountaincar" else 0)
+        cfg = EngineConfig(env_kind=kind, n_envs=n, precision=L.PRECISION_LOCKSTEP_F64 if mode == "lockstep" else L.PRECISION_F32,
+                           reset_mode=L.RESET_TAPE if env == "cartpole" else L.RESET_COUNTER_RNG, wrappers=wrappers,
+                           max_episode_steps=500 if env == "cartpole" else 200, env_offset=rank * n, seed=0)
+        eng = Engine(cfg, local_rank)
+        if env == "cartpole":
+            # reset tape rows: every episode lasts >= 8 steps, so (W+K)/8 + 2 rows can never run out
+            eng.generate_reset_tape((args.steps + args.warmup) // 8 + 2)
+        eng.reset()
+        n_act = 2 if env == "cartpole" else 3
+        g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+        acts = [torch.randint(0, n_act, (n,), dtype=torch.int32, device="cuda", generator=g) for _ in range(4)]
+        return eng, acts
+
+    def measure(env, mode):
+        eng, acts = build(env, mode)
+        dt, kern_ms = time_engine(torch, dist, eng, acts, args.steps, args.warmup, world)
+        err = eng.poll_error()
+        eps = eng.episode_stats()
+        eng.close()
+        del eng, acts
+        torch.cuda.empty_cache()
+        bps = BYTES_PER_STEP[(env, mode)]
+        achieved = bps * n / (kern_ms * 1e-3) / 1e9
+        return {
+            "value": world * n * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "kernel_ms": kern_ms,
+            "achieved_gbs": achieved, "bytes_per_env_step": bps, "error_flag": err, "episodes": eps[0],
+        }
+
+    main_m = measure(args.env, args.mode)
+    extra = {}
+    if not args.no_extra and args.env == "cartpole" and args.mode == "lockstep":
+        for env, mode in (("cartpole", "f32"), ("mountaincar", "lockstep"), ("mountaincar", "f32")):
+            m = measure(env, mode)
+            extra[f"{env}_{mode}"] = {"value": m["value"], "unit": "env-steps/s", "kernel_ms": round(m["kernel_ms"], 4),
+                                      "bytes_per_env_step": m["bytes_per_env_step"], "achieved_GBs": round(m["achieved_gbs"], 1),
+                                      "frac": round(m["achieved_gbs"] / HBM_PEAK_GBS, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        c = cpu_baseline(16384, args.cpu_seconds)
+        v, thr, nsteps, secs = c["all"]
+        cpu = {"value": v, "unit": "env-steps/s", "cores": thr, "kind": "port",
+               "sample": f"CartPole+TimeLimit(500)+Monitor, 16384 envs, {nsteps} env-steps in {secs:.1f}s, OpenMP over envs "
+                         f"(ASyncVecEnv shape); same loop on 1 core: {c['1'][0]:.3e} env-steps/s; os.cpu_count()={os.cpu_count()}"}
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(f"{args.env}_{args.mode}", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        line = {
+            "metric": "env-steps/sec (whole node), CartPole vec_env", "value": main_m["value"], "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_m["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.mode == "lockstep" else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.env} vec_env, {n} envs/GPU, TimeLimit+Monitor, fused step+auto-reset, {args.mode} arithmetic, "
+                                   f"one kernel launch per VecEnv::step (BASELINE configs[4])",
+                       "envs_per_gpu": n, "global_envs": n * world, "parallelism": f"env-shard x{world}, no data-path collective",
+                       "error_flag": main_m["error_flag"], "episodes_finished_rank0": main_m["episodes"]},
+            "roofline": {"bound": "hbm", "achieved": round(main_m["achieved_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(main_m["achieved_gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "step_kernel", "kernel_ms": round(main_m["kernel_ms"], 4),
+                         "algorithmic_bytes_per_env_step": main_m["bytes_per_env_step"]},
+            "cpu_baseline": cpu,
+            "extra": extra,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,953 @@
+// classic_control.hip — gfx950 kernels + C ABI for the batched classic-control engine.
+//
+// Hot path replaced: SyncVecEnv::stepWait's serial loop (wrappers/vec_env/sync_env.h:114-123) over
+// Monitor(ClipReward(TimeLimit(CartPoleEnv|MountainCarEnv))) objects plus VecNormalize::stepWait
+// (wrappers/vec_env/vec_normalize.h:159-177).  One env per lane; everything per-env is fused into ONE kernel
+// (dynamics, TimeLimit, ClipReward, Monitor bookkeeping, auto-reset, discounted-return lane, batch-moment partials);
+// the normaliser's grid-wide reduction splits the step into  step -> reduce -> [all-reduce] -> normalise.
+//
+// Build with -ffp-contract=off: the lockstep path must round exactly where a stock x86-64 g++ build of the reference
+// rounds (no FMA).  HBM-bound integer/float streaming work: no MFMA, no LDS tiling — coalescing and enough bytes in
+// flight are what matter.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "gymhip.h"
+#include "gymhip_internal.h"
+
+namespace gymhip {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+}  // namespace gymhip
+
+using namespace gymhip;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxGrid = 2048;  // 256 CUs x 8 resident blocks: grid-stride beyond that (guide §6 G11)
+constexpr int kMaxCols = 16;    // >= 2F+6 for F=4
+
+enum : int { KIND_CARTPOLE = GYMHIP_ENV_CARTPOLE, KIND_MOUNTAINCAR = GYMHIP_ENV_MOUNTAINCAR };
+
+// ------------------------------------------------------------------------------------------------------------
+// Reset-state generator.  TAPE rows come from the host's std::mt19937; COUNTER_RNG hashes (seed, env, episode) and
+// applies libstdc++'s uniform_real_distribution<float>(-0.05f, 0.05f) arithmetic to the 32-bit word:
+// c = float(u) / 2^32 (>= 1 -> nextafter(1,0)); value = c * (b - a) + a   (SURVEY.md §8a A3).
+// ------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline float canonical_to_range(uint32_t u) {
+    float c = (float)u * 2.3283064365386963e-10f;  // exact power-of-two scale == float(u) / 4294967296.0f
+    if (c >= 1.0f) c = 0.99999994f;
+    return c * 0.1f + (-0.05f);
+}
+__host__ __device__ inline void counter_reset_draw(uint64_t seed, int64_t global_env, int64_t episode, float (&s)[4]) {
+    uint64_t k = splitmix64(seed + (uint64_t)global_env);
+    uint64_t a = splitmix64(k ^ ((uint64_t)episode * 0xD1B54A32D192ED03ull + 1ull));
+    uint64_t b = splitmix64(a);
+    s[0] = canonical_to_range((uint32_t)a);
+    s[1] = canonical_to_range((uint32_t)(a >> 32));
+    s[2] = canonical_to_range((uint32_t)b);
+    s[3] = canonical_to_range((uint32_t)(b >> 32));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Dynamics.  State held as T[F] in registers.
+// ------------------------------------------------------------------------------------------------------------
+struct CartPoleC {  // cartpole.h:30-39 — float constants
+    static constexpr float gravity = 9.8f, masscart = 1.0f, masspole = 0.1f;
+    static constexpr float total_mass = masspole + masscart;
+    static constexpr float length = 0.5f;
+    static constexpr float polemass_length = masspole * length;
+    static constexpr float force_mag = 10.0f, tau = 0.02f;
+    static constexpr float theta_thr = (float)(12 * 2 * 3.14159265358979323846 / 360);
+    static constexpr float x_thr = 2.4f;
+};
+
+// cartpole.cpp:33-68, exact precisions (A1).  Returns the env's own `done`.
+__device__ inline bool cartpole_step(double (&s)[4], int action, int time_step) {
+    using C = CartPoleC;
+    double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
+    float force = (action == 1) ? C::force_mag : -C::force_mag;
+    double sd, cd;
+    sincos(theta, &sd, &cd);
+    float cos_t = (float)cd, sin_t = (float)sd;
+    float temp = (float)((double)force + ((double)C::polemass_length * (theta_dot * theta_dot)) * (double)sin_t) / C::total_mass;
+    float num = C::gravity * sin_t - cos_t * temp;
+    float inner = C::masspole * (cos_t * cos_t) / C::total_mass;
+    float den = (float)((double)C::length * (4.0 / 3.0 - (double)inner));
+    float theta_acc = num / den;
+    float x_acc = temp - C::polemass_length * theta_acc * cos_t / C::total_mass;
+    x = x + (double)C::tau * x_dot;
+    x_dot = x_dot + (double)(C::tau * x_acc);
+    theta = theta + (double)C::tau * theta_dot;
+    theta_dot = theta_dot + (double)(C::tau * theta_acc);
+    s[0] = x; s[1] = x_dot; s[2] = theta; s[3] = theta_dot;
+    return time_step == 500 || x < (double)(-C::x_thr) || x > (double)C::x_thr || theta < (double)(-C::theta_thr) ||
+           theta > (double)C::theta_thr;
+}
+// Same op sequence with float state (throughput mode).
+__device__ inline bool cartpole_step(float (&s)[4], int action, int time_step) {
+    using C = CartPoleC;
+    float x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
+    float force = (action == 1) ? C::force_mag : -C::force_mag;
+    float sin_t, cos_t;
+    sincosf(theta, &sin_t, &cos_t);
+    float temp = (force + C::polemass_length * (theta_dot * theta_dot) * sin_t) / C::total_mass;
+    float num = C::gravity * sin_t - cos_t * temp;
+    float inner = C::masspole * (cos_t * cos_t) / C::total_mass;
+    float den = C::length * (1.33333337f - inner);
+    float theta_acc = num / den;
+    float x_acc = temp - C::polemass_length * theta_acc * cos_t / C::total_mass;
+    x = x + C::tau * x_dot;
+    x_dot = x_dot + C::tau * x_acc;
+    theta = theta + C::tau * theta_dot;
+    theta_dot = theta_dot + C::tau * theta_acc;
+    s[0] = x; s[1] = x_dot; s[2] = theta; s[3] = theta_dot;
+    return time_step == 500 || x < -C::x_thr || x > C::x_thr || theta < -C::theta_thr || theta > C::theta_thr;
+}
+// mountain_car.cpp:17-36 (A2): float constants widened on use.
+__device__ inline bool mountaincar_step(double (&s)[2], int action) {
+    const double MIN_POS = (double)-1.2f, MAX_POS = (double)0.6f, MAX_VEL = (double)0.07f, GOAL = (double)0.5f;
+    double pos = s[0], vel = s[1];
+    vel += (action - 1) * 0.001 + cos(3 * pos) * -0.0025;
+    if (vel > MAX_VEL) vel = MAX_VEL;
+    if (vel < -MAX_VEL) vel = -MAX_VEL;
+    pos += vel;
+    if (pos > MAX_POS) pos = MAX_POS;
+    if (pos < MIN_POS) pos = MIN_POS;
+    if (pos == MIN_POS && vel < 0) vel = 0;
+    s[0] = pos; s[1] = vel;
+    return pos >= GOAL;
+}
+__device__ inline bool mountaincar_step(float (&s)[2], int action) {
+    float pos = s[0], vel = s[1];
+    vel += (float)(action - 1) * 0.001f + cosf(3.f * pos) * -0.0025f;
+    if (vel > 0.07f) vel = 0.07f;
+    if (vel < -0.07f) vel = -0.07f;
+    pos += vel;
+    if (pos > 0.6f) pos = 0.6f;
+    if (pos < -1.2f) pos = -1.2f;
+    if (pos == -1.2f && vel < 0) vel = 0;
+    s[0] = pos; s[1] = vel;
+    return pos >= 0.5f;
+}
+
+template <int KIND> struct EnvTraits;
+template <> struct EnvTraits<KIND_CARTPOLE> { static constexpr int F = 4; static constexpr float step_reward = 1.0f; };
+template <> struct EnvTraits<KIND_MOUNTAINCAR> { static constexpr int F = 2; static constexpr float step_reward = -1.0f; };
+
+// ------------------------------------------------------------------------------------------------------------
+// State I/O.  LOCKSTEP: double2 planes [F/2][N] (each plane a fully coalesced 16 B/lane stream) + f32 obs rows.
+// F32: the f32 obs rows [N][F] ARE the state (float4 / float2 per lane).
+// ------------------------------------------------------------------------------------------------------------
+template <int F> struct ObsVec;
+template <> struct ObsVec<4> { using type = float4; };
+template <> struct ObsVec<2> { using type = float2; };
+
+template <int F> __device__ inline void load_state(const StepBuffers& b, int64_t n, int64_t i, double (&s)[F]) {
+    const double2* pl = (const double2*)b.state;
+#pragma unroll
+    for (int k = 0; k < F / 2; k++) { double2 v = pl[(int64_t)k * n + i]; s[2 * k] = v.x; s[2 * k + 1] = v.y; }
+}
+template <int F> __device__ inline void store_state(const StepBuffers& b, int64_t n, int64_t i, const double (&s)[F]) {
+    double2* pl = (double2*)b.state;
+#pragma unroll
+    for (int k = 0; k < F / 2; k++) pl[(int64_t)k * n + i] = make_double2(s[2 * k], s[2 * k + 1]);
+}
+__device__ inline void load_obs(const float* obs, int64_t i, float (&s)[4]) { float4 v = ((const float4*)obs)[i]; s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w; }
+__device__ inline void load_obs(const float* obs, int64_t i, float (&s)[2]) { float2 v = ((const float2*)obs)[i]; s[0] = v.x; s[1] = v.y; }
+__device__ inline void store_obs(float* obs, int64_t i, const float (&s)[4]) { ((float4*)obs)[i] = make_float4(s[0], s[1], s[2], s[3]); }
+__device__ inline void store_obs(float* obs, int64_t i, const float (&s)[2]) { ((float2*)obs)[i] = make_float2(s[0], s[1]); }
+
+// Reset state of env i for episode `ep` (already range-checked).
+template <int KIND, typename T>
+__device__ inline void reset_state(const StepParams& p, int64_t i, int64_t ep, T (&s)[EnvTraits<KIND>::F]) {
+    if constexpr (KIND == KIND_CARTPOLE) {
+        float r[4];
+        if (p.reset_mode == GYMHIP_RESET_TAPE) {
+            float4 v = ((const float4*)p.tape)[ep * p.n + i];
+            r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+        } else {
+            counter_reset_draw(p.seed, p.env_offset + i, ep, r);
+        }
+#pragma unroll
+        for (int f = 0; f < 4; f++) s[f] = (T)r[f];  // float widened into the double state (cartpole.cpp:23-26)
+    } else {
+        s[0] = (T)-0.5; s[1] = (T)0.0;  // mountain_car.cpp:38-42
+    }
+}
+
+// Wave/block reduction of per-thread double columns into partials[blockIdx][cols] in a fixed order (deterministic).
+template <int COLS>
+__device__ inline void block_reduce_store(double (&v)[COLS], double* out_row, bool accumulate) {
+    __shared__ double red[kBlock / 64][COLS];
+#pragma unroll
+    for (int c = 0; c < COLS; c++) {
+        double x = v[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        v[c] = x;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < COLS; c++) red[wave][c] = v[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < COLS) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) t += red[w][threadIdx.x];
+        if (accumulate) t += out_row[threadIdx.x];
+        out_row[threadIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Kernel A: one VecEnv::step for every env.
+// ------------------------------------------------------------------------------------------------------------
+template <int KIND, bool LOCKSTEP, typename ActT, bool NORM>
+__global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
+    constexpr int F = EnvTraits<KIND>::F;
+    using T = typename std::conditional<LOCKSTEP, double, float>::type;
+    constexpr int NCOL = NORM ? 2 * F + 2 : 1;
+    double acc[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; c++) acc[c] = 0.0;
+    double ep[3] = {0.0, 0.0, 0.0};
+    float shift[F + 1];
+    if constexpr (NORM) {
+#pragma unroll
+        for (int f = 0; f < F; f++) shift[f] = p.stats_cur[f];
+        shift[F] = p.stats_cur[2 * F + 1];
+    }
+    const ActT* actions = (const ActT*)p.actions;
+    const StepBuffers& b = p.buf;
+    const bool time_limit = p.wrappers & GYMHIP_WRAP_TIME_LIMIT;
+    const bool clip = p.wrappers & GYMHIP_WRAP_CLIP_REWARD;
+    const bool monitor = p.wrappers & GYMHIP_WRAP_MONITOR;
+    const bool ret_lane = (p.wrappers & GYMHIP_WRAP_NORM_REWARD) && (p.wrappers & GYMHIP_WRAP_NORM_TRAINING);
+
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * kBlock) {
+        T s[F];
+        if constexpr (LOCKSTEP) load_state<F>(b, p.n, i, s); else load_obs(b.obs, i, s);
+        const int action = (int)actions[i];
+        int t = b.elapsed[i];
+
+        bool env_done;
+        if constexpr (KIND == KIND_CARTPOLE) env_done = cartpole_step(s, action, t); else env_done = mountaincar_step(s, action);
+        t += 1;
+        bool done = env_done, trunc = false;
+        if (time_limit && t >= p.max_episode_steps) { trunc = !env_done; done = true; }   // time_limit.h:30-34
+        float reward = EnvTraits<KIND>::step_reward;
+        if (clip) reward = reward == 0.f ? reward : (reward > 0.f ? 1.f : -1.f);           // clip_reward.h:22-24
+        (void)clip;
+
+        if (done) {
+            // Monitor (monitor.h:78-97): every step of these envs pays the same reward, so the ordered float sum of
+            // t copies equals float(t)*reward exactly (t < 2^24).
+            const float ep_ret = (float)t * reward;
+            if (monitor) { b.last_ep_return[i] = ep_ret; b.last_ep_length[i] = t; }
+            b.truncated[i] = trunc ? 1 : 0;
+            ep[0] += 1.0; ep[1] += (double)ep_ret; ep[2] += (double)t;
+            int64_t e = b.episode_index[i];
+            b.episode_index[i] = (int32_t)(e + 1);
+            if (KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE && e >= p.tape_episodes) {
+                atomicOr(p.error_flag, 1);
+                e = e % p.tape_episodes;
+            }
+            reset_state<KIND, T>(p, i, e, s);   // sync_env.h:92-100: terminal obs replaced by the reset obs
+            t = 0;
+        }
+
+        float o[F];
+#pragma unroll
+        for (int f = 0; f < F; f++) o[f] = (float)s[f];
+        if constexpr (LOCKSTEP) store_state<F>(b, p.n, i, s);
+        store_obs(b.obs, i, o);
+        b.elapsed[i] = t;
+        b.reward[i] = reward;
+        b.done[i] = done ? 1.f : 0.f;
+
+        if constexpr (NORM) {
+#pragma unroll
+            for (int f = 0; f < F; f++) { double d = (double)o[f] - (double)shift[f]; acc[f] += d; acc[F + f] += d * d; }
+            if (ret_lane) {
+                float r = b.returns[i] * p.gamma + reward;        // vec_normalize.h:132
+                double d = (double)r - (double)shift[F];
+                acc[2 * F] += d; acc[2 * F + 1] += d * d;
+                b.returns[i] = done ? 0.f : r;                    // vec_normalize.h:175 (applied after the RMS update)
+            }
+        }
+    }
+
+    if constexpr (NORM) {
+        double cols[2 * F + 5];
+#pragma unroll
+        for (int c = 0; c < 2 * F + 2; c++) cols[c] = acc[c];
+        cols[2 * F + 2] = ep[0]; cols[2 * F + 3] = ep[1]; cols[2 * F + 4] = ep[2];
+        block_reduce_store<2 * F + 5>(cols, p.partials + (int64_t)blockIdx.x * kMaxCols, false);
+    }
+    // cumulative per-block episode counters (owner-block read-modify-write: no atomics, deterministic)
+    block_reduce_store<3>(ep, p.ep_partials + (int64_t)blockIdx.x * 4, true);
+}
+
+// Initial reset (VecEnv::reset): episode 0 for every env.
+template <int KIND, bool LOCKSTEP, bool NORM>
+__global__ __launch_bounds__(kBlock) void reset_kernel(const StepParams p) {
+    constexpr int F = EnvTraits<KIND>::F;
+    using T = typename std::conditional<LOCKSTEP, double, float>::type;
+    constexpr int NCOL = NORM ? 2 * F + 2 : 1;
+    double acc[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; c++) acc[c] = 0.0;
+    float shift[F];
+    if constexpr (NORM) {
+#pragma unroll
+        for (int f = 0; f < F; f++) shift[f] = p.stats_cur[f];
+    }
+    const StepBuffers& b = p.buf;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * kBlock) {
+        T s[F];
+        reset_state<KIND, T>(p, i, 0, s);
+        float o[F];
+#pragma unroll
+        for (int f = 0; f < F; f++) o[f] = (float)s[f];
+        if constexpr (LOCKSTEP) store_state<F>(b, p.n, i, s);
+        store_obs(b.obs, i, o);
+        b.elapsed[i] = 0;
+        b.episode_index[i] = 1;
+        b.reward[i] = 0.f;
+        b.done[i] = 0.f;
+        b.truncated[i] = 0;
+        b.last_ep_return[i] = 0.f;
+        b.last_ep_length[i] = 0;
+        if (b.returns) b.returns[i] = 0.f;                        // vec_normalize.h:147
+        if constexpr (NORM) {
+#pragma unroll
+            for (int f = 0; f < F; f++) { double d = (double)o[f] - (double)shift[f]; acc[f] += d; acc[F + f] += d * d; }
+        }
+    }
+    if constexpr (NORM) {
+        double cols[2 * F + 5];
+#pragma unroll
+        for (int c = 0; c < 2 * F + 2; c++) cols[c] = acc[c];
+        cols[2 * F + 2] = 0; cols[2 * F + 3] = 0; cols[2 * F + 4] = 0;
+        block_reduce_store<2 * F + 5>(cols, p.partials + (int64_t)blockIdx.x * kMaxCols, false);
+    }
+}
+
+// Kernel F: partials[grid][kMaxCols] -> moments[0] = n_local, moments[1 + c] = column sums.  One block, fixed order.
+__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double* partials, int rows, int cols, double n_local, double* moments) {
+    __shared__ double red[16][kMaxCols];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;  // 16 row groups x 16 columns
+    double t = 0;
+    if (c < cols) for (int r = g; r < rows; r += 16) t += partials[(int64_t)r * kMaxCols + c];
+    red[g][c] = t;
+    __syncthreads();
+    if (threadIdx.x < cols) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) s += red[k][threadIdx.x];
+        moments[1 + threadIdx.x] = s;
+    }
+    if (threadIdx.x == 0) moments[0] = n_local;
+}
+
+// RunningMeanStd::updateFromMoment in float32, evaluation order as written (running_mean_std.h:50-57, A9).
+__device__ inline void rms_update(float& mean, float& var, float count, float bm, float bv, float nf, float tot) {
+    float delta = bm - mean;
+    float new_mean = mean + delta * nf / tot;
+    float ma = var * count;
+    float mb = bv * nf;
+    float m2 = ma + mb + delta * delta * count * nf / tot;
+    var = m2 / tot;
+    mean = new_mean;
+}
+
+// Kernel B: apply the (all-reduced) batch moments to the running statistics, then normalise (vec_normalize.h:118-129).
+// Every block derives the new statistics redundantly (identical instructions on identical inputs); block 0 publishes
+// them into the other ping-pong slot, which only the NEXT launches read.
+template <int F>
+__global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
+    float mean[F], var[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) { mean[f] = q.stats_cur[f]; var[f] = q.stats_cur[F + f]; }
+    float ocount = q.stats_cur[2 * F], rmean = q.stats_cur[2 * F + 1], rvar = q.stats_cur[2 * F + 2], rcount = q.stats_cur[2 * F + 3];
+    const double n = q.moments[0];
+    const float nf = (float)n;
+    if (q.update_obs) {
+        const float tot = ocount + nf;
+#pragma unroll
+        for (int f = 0; f < F; f++) {
+            double m1 = q.moments[1 + f] / n, m2 = q.moments[1 + F + f] / n;
+            double v = m2 - m1 * m1;
+            float bm = (float)((double)mean[f] + m1), bv = (float)(v > 0 ? v : 0.0);
+            rms_update(mean[f], var[f], ocount, bm, bv, nf, tot);
+        }
+        ocount = tot;
+    }
+    if (q.update_ret) {
+        const float tot = rcount + nf;
+        double m1 = q.moments[1 + 2 * F] / n, m2 = q.moments[2 + 2 * F] / n;
+        double v = m2 - m1 * m1;
+        float bm = (float)((double)rmean + m1), bv = (float)(v > 0 ? v : 0.0);
+        rms_update(rmean, rvar, rcount, bm, bv, nf, tot);
+        rcount = tot;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float* outs[2] = {q.stats_next, q.stats_public};
+        for (int k = 0; k < 2; k++) {
+            float* o = outs[k];
+#pragma unroll
+            for (int f = 0; f < F; f++) { o[f] = mean[f]; o[F + f] = var[f]; }
+            o[2 * F] = ocount; o[2 * F + 1] = rmean; o[2 * F + 2] = rvar; o[2 * F + 3] = rcount;
+        }
+        if (q.ep_totals_global) {
+            q.ep_totals_global[0] += q.moments[2 * F + 3]; q.ep_totals_global[1] += q.moments[2 * F + 4]; q.ep_totals_global[2] += q.moments[2 * F + 5];
+        }
+    }
+    float inv_sd[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) inv_sd[f] = sqrtf(var[f] + q.epsilon);   // divisor, not reciprocal: keep the reference's divide
+    const float rsd = sqrtf(rvar + q.epsilon);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < q.n; i += (int64_t)gridDim.x * kBlock) {
+        if (q.norm_obs) {
+            float o[F];
+            load_obs(q.obs, i, o);
+#pragma unroll
+            for (int f = 0; f < F; f++) o[f] = fminf(fmaxf((o[f] - mean[f]) / inv_sd[f], -q.clip_obs), q.clip_obs);
+            store_obs(q.obs_norm, i, o);
+        }
+        if (q.norm_reward) q.reward[i] = fminf(fmaxf(q.reward[i] / rsd, -q.clip_reward), q.clip_reward);
+    }
+}
+
+// K steps in one launch; state lives in registers between steps.
+template <int KIND, bool LOCKSTEP>
+__global__ __launch_bounds__(kBlock) void rollout_kernel(const StepParams p, const uint8_t* __restrict__ tape, int64_t K,
+                                                          uint8_t* rec_done, float* rec_reward, uint8_t* rec_trunc, float* rec_obs) {
+    constexpr int F = EnvTraits<KIND>::F;
+    using T = typename std::conditional<LOCKSTEP, double, float>::type;
+    const StepBuffers& b = p.buf;
+    const bool time_limit = p.wrappers & GYMHIP_WRAP_TIME_LIMIT;
+    const bool clip = p.wrappers & GYMHIP_WRAP_CLIP_REWARD;
+    const bool monitor = p.wrappers & GYMHIP_WRAP_MONITOR;
+    double ep[3] = {0.0, 0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * kBlock) {
+        T s[F];
+        if constexpr (LOCKSTEP) load_state<F>(b, p.n, i, s); else load_obs(b.obs, i, s);
+        int t = b.elapsed[i];
+        int64_t e = b.episode_index[i];
+        float reward = 0.f; bool done = false; bool any_done = false; bool last_trunc = false; float last_ret = 0.f; int last_len = 0;
+        for (int64_t k = 0; k < K; k++) {
+            const int action = (int)tape[k * p.n + i];
+            bool env_done;
+            if constexpr (KIND == KIND_CARTPOLE) env_done = cartpole_step(s, action, t); else env_done = mountaincar_step(s, action);
+            t += 1;
+            done = env_done; bool trunc = false;
+            if (time_limit && t >= p.max_episode_steps) { trunc = !env_done; done = true; }
+            reward = EnvTraits<KIND>::step_reward;
+            if (clip) reward = reward == 0.f ? reward : (reward > 0.f ? 1.f : -1.f);
+            if (done) {
+                last_ret = (float)t * reward; last_len = t; last_trunc = trunc; any_done = true;
+                ep[0] += 1.0; ep[1] += (double)last_ret; ep[2] += (double)t;
+                int64_t er = e;
+                if (KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE && er >= p.tape_episodes) { atomicOr(p.error_flag, 1); er = er % p.tape_episodes; }
+                reset_state<KIND, T>(p, i, er, s);
+                e += 1; t = 0;
+            }
+            if (rec_done) rec_done[k * p.n + i] = done;
+            if (rec_reward) rec_reward[k * p.n + i] = reward;
+            if (rec_trunc) rec_trunc[k * p.n + i] = trunc;
+            if (rec_obs) {
+                float o[F];
+#pragma unroll
+                for (int f = 0; f < F; f++) o[f] = (float)s[f];
+                store_obs(rec_obs + k * p.n * F, i, o);
+            }
+        }
+        float o[F];
+#pragma unroll
+        for (int f = 0; f < F; f++) o[f] = (float)s[f];
+        if constexpr (LOCKSTEP) store_state<F>(b, p.n, i, s);
+        store_obs(b.obs, i, o);
+        b.elapsed[i] = t;
+        b.episode_index[i] = (int32_t)e;
+        b.reward[i] = reward;
+        b.done[i] = done ? 1.f : 0.f;
+        if (any_done) {   // "valid where done" lanes describe the env's most recent finished episode
+            b.truncated[i] = last_trunc;
+            if (monitor) { b.last_ep_return[i] = last_ret; b.last_ep_length[i] = last_len; }
+        }
+    }
+    block_reduce_store<3>(ep, p.ep_partials + (int64_t)blockIdx.x * 4, true);
+}
+
+__global__ __launch_bounds__(kBlock) void reduce_episode_kernel(const double* ep_partials, int rows, const double* extra, double* totals) {
+    __shared__ double red[kBlock][3];
+    double t[3] = {0, 0, 0};
+    for (int r = threadIdx.x; r < rows; r += kBlock) { t[0] += ep_partials[r * 4]; t[1] += ep_partials[r * 4 + 1]; t[2] += ep_partials[r * 4 + 2]; }
+    red[threadIdx.x][0] = t[0]; red[threadIdx.x][1] = t[1]; red[threadIdx.x][2] = t[2];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double s = 0;
+        for (int k = 0; k < kBlock; k++) s += red[k][threadIdx.x];
+        totals[threadIdx.x] = s;
+    }
+    (void)extra;
+}
+
+__global__ __launch_bounds__(kBlock) void fill_tape_kernel(float4* tape, int64_t n, int64_t episodes, uint64_t seed, int64_t env_offset) {
+    const int64_t total = n * episodes;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < total; j += (int64_t)gridDim.x * kBlock) {
+        const int64_t epi = j / n, i = j - epi * n;
+        float r[4];
+        counter_reset_draw(seed, env_offset + i, epi, r);
+        tape[j] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------------------------------
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Layout {
+    size_t state, obs, obs_norm, reward, done, truncated, elapsed, episode_index, last_ep_return, last_ep_length, returns;
+    size_t stats /*3 slots*/, moments, partials, ep_partials, ep_totals, ep_totals_global, error_flag, total;
+};
+
+int obs_dim_of(int kind) { return kind == KIND_CARTPOLE ? 4 : 2; }
+
+bool valid_config(const gymhip_config* c) {
+    if (!c || c->struct_size != (int32_t)sizeof(gymhip_config)) return false;
+    if (c->env_kind != KIND_CARTPOLE && c->env_kind != KIND_MOUNTAINCAR) return false;
+    if (c->precision != GYMHIP_PRECISION_LOCKSTEP_F64 && c->precision != GYMHIP_PRECISION_F32) return false;
+    if (c->reset_mode != GYMHIP_RESET_TAPE && c->reset_mode != GYMHIP_RESET_COUNTER_RNG) return false;
+    if (c->n_envs <= 0 || c->env_offset < 0) return false;
+    if ((c->wrappers & GYMHIP_WRAP_TIME_LIMIT) && c->max_episode_steps <= 0) return false;
+    return true;
+}
+
+int grid_for(int64_t n) {
+    int64_t g = (n + kBlock - 1) / kBlock;
+    return (int)(g < kMaxGrid ? g : kMaxGrid);
+}
+
+Layout make_layout(const gymhip_config& c) {
+    Layout L{};
+    const size_t n = (size_t)c.n_envs, F = (size_t)obs_dim_of(c.env_kind);
+    const bool lock = c.precision == GYMHIP_PRECISION_LOCKSTEP_F64;
+    const bool norm = c.wrappers & (GYMHIP_WRAP_NORM_OBS | GYMHIP_WRAP_NORM_REWARD);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
+    L.obs = take(n * F * 4);
+    L.state = lock ? take(n * F * 8) : L.obs;
+    L.obs_norm = (c.wrappers & GYMHIP_WRAP_NORM_OBS) ? take(n * F * 4) : (size_t)-1;
+    L.reward = take(n * 4);
+    L.done = take(n * 4);
+    L.truncated = take(n);
+    L.elapsed = take(n * 4);
+    L.episode_index = take(n * 4);
+    L.last_ep_return = take(n * 4);
+    L.last_ep_length = take(n * 4);
+    L.returns = (c.wrappers & GYMHIP_WRAP_NORM_REWARD) ? take(n * 4) : (size_t)-1;
+    L.stats = norm ? take(3 * 16 * 4) : (size_t)-1;
+    L.moments = take(kMaxCols * 8);
+    L.partials = norm ? take((size_t)kMaxGrid * kMaxCols * 8) : (size_t)-1;
+    L.ep_partials = take((size_t)kMaxGrid * 4 * 8);
+    L.ep_totals = take(4 * 8);
+    L.ep_totals_global = take(4 * 8);
+    L.error_flag = take(4);
+    L.total = off;
+    return L;
+}
+
+}  // namespace
+
+struct gymhip_engine {
+    gymhip_config cfg;
+    int device;
+    int F;
+    bool owns_ws;
+    char* ws;
+    size_t ws_bytes;
+    Layout L;
+    int grid;
+    bool norm;
+    int stats_slot;          // ping-pong slot holding the current running statistics
+    float* tape;
+    int64_t tape_episodes;
+    bool did_reset;
+    bool pending_finish;     // a *_begin with the normaliser on awaits its *_finish
+    bool pending_is_reset;
+
+    template <typename T> T* at(size_t off) const { return off == (size_t)-1 ? nullptr : (T*)(ws + off); }
+    float* stats_slot_ptr(int s) const { return at<float>(L.stats) + 16 * s; }
+};
+
+namespace {
+
+StepParams make_params(gymhip_engine* h) {
+    StepParams p{};
+    p.n = h->cfg.n_envs;
+    p.env_offset = h->cfg.env_offset;
+    p.seed = h->cfg.seed;
+    p.wrappers = h->cfg.wrappers;
+    p.max_episode_steps = h->cfg.max_episode_steps;
+    p.reset_mode = h->cfg.reset_mode;
+    p.gamma = h->cfg.gamma;
+    p.tape = h->tape;
+    p.tape_episodes = h->tape_episodes;
+    p.error_flag = h->at<int32_t>(h->L.error_flag);
+    p.partials = h->at<double>(h->L.partials);
+    p.ep_partials = h->at<double>(h->L.ep_partials);
+    p.stats_cur = h->norm ? h->stats_slot_ptr(h->stats_slot) : nullptr;
+    StepBuffers& b = p.buf;
+    b.state = h->at<void>(h->L.state);
+    b.obs = h->at<float>(h->L.obs);
+    b.reward = h->at<float>(h->L.reward);
+    b.done = h->at<float>(h->L.done);
+    b.truncated = h->at<uint8_t>(h->L.truncated);
+    b.elapsed = h->at<int32_t>(h->L.elapsed);
+    b.episode_index = h->at<int32_t>(h->L.episode_index);
+    b.last_ep_return = h->at<float>(h->L.last_ep_return);
+    b.last_ep_length = h->at<int32_t>(h->L.last_ep_length);
+    b.returns = h->at<float>(h->L.returns);
+    return p;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(GYMHIP_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int check_handle(gymhip_engine* h) {
+    if (!h) return fail(GYMHIP_EINVAL, "null engine handle");
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return fail(GYMHIP_EHIP, "hipSetDevice(%d) failed: %s", h->device, hipGetErrorString(e));
+    return GYMHIP_OK;
+}
+
+template <int KIND, bool LOCKSTEP, bool NORM>
+void launch_step_act(gymhip_engine* h, const StepParams& p, int action_dtype, hipStream_t s) {
+    switch (action_dtype) {
+        case GYMHIP_ACT_I32: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, int32_t, NORM>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
+        case GYMHIP_ACT_I64: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, int64_t, NORM>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
+        default: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, uint8_t, NORM>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
+    }
+}
+template <int KIND, bool LOCKSTEP>
+void launch_step_norm(gymhip_engine* h, const StepParams& p, int action_dtype, hipStream_t s) {
+    if (h->norm) launch_step_act<KIND, LOCKSTEP, true>(h, p, action_dtype, s);
+    else launch_step_act<KIND, LOCKSTEP, false>(h, p, action_dtype, s);
+}
+template <int KIND>
+void launch_step_kind(gymhip_engine* h, const StepParams& p, int action_dtype, hipStream_t s) {
+    if (h->cfg.precision == GYMHIP_PRECISION_LOCKSTEP_F64) launch_step_norm<KIND, true>(h, p, action_dtype, s);
+    else launch_step_norm<KIND, false>(h, p, action_dtype, s);
+}
+
+template <int KIND, bool LOCKSTEP>
+void launch_reset_norm(gymhip_engine* h, const StepParams& p, hipStream_t s) {
+    if (h->norm) hipLaunchKernelGGL((reset_kernel<KIND, LOCKSTEP, true>), dim3(h->grid), dim3(kBlock), 0, s, p);
+    else hipLaunchKernelGGL((reset_kernel<KIND, LOCKSTEP, false>), dim3(h->grid), dim3(kBlock), 0, s, p);
+}
+template <int KIND>
+void launch_reset_kind(gymhip_engine* h, const StepParams& p, hipStream_t s) {
+    if (h->cfg.precision == GYMHIP_PRECISION_LOCKSTEP_F64) launch_reset_norm<KIND, true>(h, p, s);
+    else launch_reset_norm<KIND, false>(h, p, s);
+}
+
+void launch_reduce_partials(gymhip_engine* h, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, s, h->at<double>(h->L.partials), h->grid, 2 * h->F + 5,
+                       (double)h->cfg.n_envs, h->at<double>(h->L.moments));
+}
+
+int launch_normalize(gymhip_engine* h, bool is_reset, hipStream_t s) {
+    const uint32_t w = h->cfg.wrappers;
+    const bool training = w & GYMHIP_WRAP_NORM_TRAINING;
+    NormParams q{};
+    q.n = h->cfg.n_envs;
+    q.stats_cur = h->stats_slot_ptr(h->stats_slot);
+    q.stats_next = h->stats_slot_ptr(h->stats_slot ^ 1);
+    q.stats_public = h->stats_slot_ptr(2);
+    q.moments = h->at<double>(h->L.moments);
+    q.ep_totals_global = is_reset ? nullptr : h->at<double>(h->L.ep_totals_global);
+    q.obs = h->at<float>(h->L.obs);
+    q.obs_norm = h->at<float>(h->L.obs_norm);
+    q.reward = h->at<float>(h->L.reward);
+    q.clip_obs = h->cfg.clip_obs; q.clip_reward = h->cfg.clip_reward; q.epsilon = h->cfg.epsilon;
+    q.norm_obs = (w & GYMHIP_WRAP_NORM_OBS) != 0;
+    q.norm_reward = !is_reset && (w & GYMHIP_WRAP_NORM_REWARD);
+    q.update_obs = training && (w & GYMHIP_WRAP_NORM_OBS);                       // vec_normalize.h:149-151,162-164
+    q.update_ret = !is_reset && training && (w & GYMHIP_WRAP_NORM_REWARD);       // vec_normalize.h:169-170
+    if (h->F == 4) hipLaunchKernelGGL(normalize_kernel<4>, dim3(h->grid), dim3(kBlock), 0, s, q);
+    else hipLaunchKernelGGL(normalize_kernel<2>, dim3(h->grid), dim3(kBlock), 0, s, q);
+    h->stats_slot ^= 1;  // the kernel always publishes the (possibly unchanged) statistics into the other slot
+    return GYMHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gymhip_last_error(void) { return g_last_error.c_str(); }
+int gymhip_version(void) { return 1; }
+
+size_t gymhip_workspace_bytes(const gymhip_config* cfg) {
+    if (!valid_config(cfg)) return 0;
+    return make_layout(*cfg).total;
+}
+
+int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t workspace_bytes, gymhip_engine** out) {
+    if (!out) return fail(GYMHIP_EINVAL, "out is null");
+    *out = nullptr;
+    if (!valid_config(cfg)) return fail(GYMHIP_EINVAL, "invalid gymhip_config (struct_size/env_kind/precision/reset_mode/n_envs/max_episode_steps)");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(GYMHIP_EINVAL, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    gymhip_engine* h = new (std::nothrow) gymhip_engine();
+    if (!h) return fail(GYMHIP_EINVAL, "out of host memory");
+    h->cfg = *cfg;
+    h->device = device;
+    h->F = obs_dim_of(cfg->env_kind);
+    h->L = make_layout(*cfg);
+    h->grid = grid_for(cfg->n_envs);
+    h->norm = cfg->wrappers & (GYMHIP_WRAP_NORM_OBS | GYMHIP_WRAP_NORM_REWARD);
+    h->stats_slot = 0;
+    h->tape = nullptr; h->tape_episodes = 0;
+    h->did_reset = false; h->pending_finish = false; h->pending_is_reset = false;
+    if (workspace) {
+        if (workspace_bytes < h->L.total || ((uintptr_t)workspace & 255)) { delete h; return fail(GYMHIP_EINVAL, "workspace too small (%zu < %zu) or not 256-B aligned", workspace_bytes, h->L.total); }
+        h->ws = (char*)workspace; h->owns_ws = false;
+    } else {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, h->L.total);
+        if (e != hipSuccess) { delete h; return fail(GYMHIP_EHIP, "hipMalloc(%zu) failed: %s", h->L.total, hipGetErrorString(e)); }
+        h->ws = (char*)p; h->owns_ws = true;
+    }
+    h->ws_bytes = h->L.total;
+    hipError_t e = hipMemset(h->ws, 0, h->L.total);
+    if (e == hipSuccess && h->norm) {
+        // RunningMeanStd ctor (running_mean_std.h:16-20): mean 0, var 1, count 1e-4 — obs and return statistics
+        float init[16] = {0};
+        for (int f = 0; f < h->F; f++) { init[f] = 0.f; init[h->F + f] = 1.f; }
+        init[2 * h->F] = 1e-4f; init[2 * h->F + 1] = 0.f; init[2 * h->F + 2] = 1.f; init[2 * h->F + 3] = 1e-4f;
+        for (int s = 0; s < 3 && e == hipSuccess; s++) e = hipMemcpy(h->stats_slot_ptr(s), init, sizeof init, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) { if (h->owns_ws) (void)hipFree(h->ws); delete h; return fail(GYMHIP_EHIP, "workspace init failed: %s", hipGetErrorString(e)); }
+    *out = h;
+    return GYMHIP_OK;
+}
+
+int gymhip_destroy(gymhip_engine* h) {
+    if (!h) return GYMHIP_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    if (h->tape) (void)hipFree(h->tape);
+    if (h->owns_ws) (void)hipFree(h->ws);
+    delete h;
+    return GYMHIP_OK;
+}
+
+int gymhip_get_buffers(gymhip_engine* h, gymhip_buffers* out) {
+    if (!h || !out) return fail(GYMHIP_EINVAL, "null argument");
+    std::memset(out, 0, sizeof *out);
+    out->obs_dim = h->F;
+    out->moments_len = 1 + 2 * h->F + 5;
+    out->state = h->at<void>(h->L.state);
+    out->obs = h->at<float>(h->L.obs);
+    out->obs_norm = h->at<float>(h->L.obs_norm);
+    out->reward = h->at<float>(h->L.reward);
+    out->done = h->at<float>(h->L.done);
+    out->truncated = h->at<uint8_t>(h->L.truncated);
+    out->elapsed_steps = h->at<int32_t>(h->L.elapsed);
+    out->episode_index = h->at<int32_t>(h->L.episode_index);
+    out->last_episode_return = h->at<float>(h->L.last_ep_return);
+    out->last_episode_length = h->at<int32_t>(h->L.last_ep_length);
+    out->returns = h->at<float>(h->L.returns);
+    out->norm_stats = h->norm ? h->stats_slot_ptr(2) : nullptr;
+    out->moments = h->at<double>(h->L.moments);
+    out->episode_totals = h->at<double>(h->L.ep_totals);
+    return GYMHIP_OK;
+}
+
+int gymhip_seed(gymhip_engine* h, uint64_t seed) {
+    if (!h) return fail(GYMHIP_EINVAL, "null engine handle");
+    h->cfg.seed = seed;
+    return GYMHIP_OK;
+}
+
+static int ensure_tape(gymhip_engine* h, int64_t episodes) {
+    if (h->cfg.env_kind != KIND_CARTPOLE) return fail(GYMHIP_EINVAL, "only CartPole draws its reset state (MountainCar resets are constant)");
+    if (episodes <= 0) return fail(GYMHIP_EINVAL, "episodes must be positive");
+    if (h->tape && h->tape_episodes != episodes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(h->tape)); h->tape = nullptr; h->tape_episodes = 0; }
+    if (!h->tape) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, (size_t)episodes * h->cfg.n_envs * 16));
+        h->tape = (float*)p; h->tape_episodes = episodes;
+    }
+    return GYMHIP_OK;
+}
+
+int gymhip_upload_reset_tape(gymhip_engine* h, const float* host_tape, int64_t episodes) {
+    if (int rc = check_handle(h)) return rc;
+    if (!host_tape) return fail(GYMHIP_EINVAL, "host_tape is null");
+    if (int rc = ensure_tape(h, episodes)) return rc;
+    HIP_TRY(hipMemcpy(h->tape, host_tape, (size_t)episodes * h->cfg.n_envs * 16, hipMemcpyHostToDevice));
+    return GYMHIP_OK;
+}
+
+int gymhip_generate_reset_tape(gymhip_engine* h, int64_t episodes, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = ensure_tape(h, episodes)) return rc;
+    hipLaunchKernelGGL(fill_tape_kernel, dim3(kMaxGrid), dim3(kBlock), 0, (hipStream_t)stream, (float4*)h->tape, h->cfg.n_envs, episodes, h->cfg.seed, h->cfg.env_offset);
+    HIP_TRY(hipGetLastError());
+    return GYMHIP_OK;
+}
+
+int gymhip_download_reset_tape(gymhip_engine* h, float* host_tape, int64_t episodes) {
+    if (int rc = check_handle(h)) return rc;
+    if (!host_tape || !h->tape || episodes > h->tape_episodes || episodes <= 0) return fail(GYMHIP_EINVAL, "no device tape of that size");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_tape, h->tape, (size_t)episodes * h->cfg.n_envs * 16, hipMemcpyDeviceToHost));
+    return GYMHIP_OK;
+}
+
+int gymhip_reset_begin(gymhip_engine* h, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (h->pending_finish) return fail(GYMHIP_ESTATE, "previous *_begin has no matching *_finish");
+    if (h->cfg.env_kind == KIND_CARTPOLE && h->cfg.reset_mode == GYMHIP_RESET_TAPE && !h->tape)
+        return fail(GYMHIP_ETAPE, "reset_mode TAPE but no reset tape uploaded (gymhip_upload_reset_tape)");
+    hipStream_t s = (hipStream_t)stream;
+    StepParams p = make_params(h);
+    if (h->cfg.env_kind == KIND_CARTPOLE) launch_reset_kind<KIND_CARTPOLE>(h, p, s); else launch_reset_kind<KIND_MOUNTAINCAR>(h, p, s);
+    if (h->norm) launch_reduce_partials(h, s);
+    HIP_TRY(hipGetLastError());
+    h->did_reset = true;
+    h->pending_finish = h->norm; h->pending_is_reset = true;
+    return GYMHIP_OK;
+}
+
+int gymhip_step_begin(gymhip_engine* h, const void* actions, int action_dtype, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (!actions) return fail(GYMHIP_EINVAL, "actions is null");
+    if (action_dtype < GYMHIP_ACT_I32 || action_dtype > GYMHIP_ACT_U8) return fail(GYMHIP_EINVAL, "unknown action_dtype %d", action_dtype);
+    if (!h->did_reset) return fail(GYMHIP_ESTATE, "step before reset");
+    if (h->pending_finish) return fail(GYMHIP_ESTATE, "previous *_begin has no matching *_finish");
+    hipStream_t s = (hipStream_t)stream;
+    StepParams p = make_params(h);
+    p.actions = actions;
+    if (h->cfg.env_kind == KIND_CARTPOLE) launch_step_kind<KIND_CARTPOLE>(h, p, action_dtype, s); else launch_step_kind<KIND_MOUNTAINCAR>(h, p, action_dtype, s);
+    if (h->norm) launch_reduce_partials(h, s);
+    HIP_TRY(hipGetLastError());
+    h->pending_finish = h->norm; h->pending_is_reset = false;
+    return GYMHIP_OK;
+}
+
+static int finish_common(gymhip_engine* h, bool is_reset, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->norm) return GYMHIP_OK;
+    if (!h->pending_finish || h->pending_is_reset != is_reset) return fail(GYMHIP_ESTATE, "*_finish without the matching *_begin");
+    launch_normalize(h, is_reset, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    h->pending_finish = false;
+    return GYMHIP_OK;
+}
+int gymhip_step_finish(gymhip_engine* h, void* stream) { return finish_common(h, false, stream); }
+int gymhip_reset_finish(gymhip_engine* h, void* stream) { return finish_common(h, true, stream); }
+
+int gymhip_reset(gymhip_engine* h, void* stream) {
+    if (int rc = gymhip_reset_begin(h, stream)) return rc;
+    return gymhip_reset_finish(h, stream);
+}
+int gymhip_step(gymhip_engine* h, const void* actions, int action_dtype, void* stream) {
+    if (int rc = gymhip_step_begin(h, actions, action_dtype, stream)) return rc;
+    return gymhip_step_finish(h, stream);
+}
+
+int gymhip_rollout(gymhip_engine* h, const uint8_t* action_tape, int64_t k_steps, uint8_t* rec_done, float* rec_reward,
+                   uint8_t* rec_truncated, float* rec_obs, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (!action_tape || k_steps <= 0) return fail(GYMHIP_EINVAL, "action_tape null or k_steps <= 0");
+    if (h->norm) return fail(GYMHIP_EINVAL, "rollout is not available with the normaliser (needs a grid-wide reduction per step)");
+    if (!h->did_reset) return fail(GYMHIP_ESTATE, "rollout before reset");
+    hipStream_t s = (hipStream_t)stream;
+    StepParams p = make_params(h);
+    const bool lock = h->cfg.precision == GYMHIP_PRECISION_LOCKSTEP_F64;
+    dim3 g(h->grid), bdim(kBlock);
+    if (h->cfg.env_kind == KIND_CARTPOLE) {
+        if (lock) hipLaunchKernelGGL((rollout_kernel<KIND_CARTPOLE, true>), g, bdim, 0, s, p, action_tape, k_steps, rec_done, rec_reward, rec_truncated, rec_obs);
+        else hipLaunchKernelGGL((rollout_kernel<KIND_CARTPOLE, false>), g, bdim, 0, s, p, action_tape, k_steps, rec_done, rec_reward, rec_truncated, rec_obs);
+    } else {
+        if (lock) hipLaunchKernelGGL((rollout_kernel<KIND_MOUNTAINCAR, true>), g, bdim, 0, s, p, action_tape, k_steps, rec_done, rec_reward, rec_truncated, rec_obs);
+        else hipLaunchKernelGGL((rollout_kernel<KIND_MOUNTAINCAR, false>), g, bdim, 0, s, p, action_tape, k_steps, rec_done, rec_reward, rec_truncated, rec_obs);
+    }
+    HIP_TRY(hipGetLastError());
+    return GYMHIP_OK;
+}
+
+int gymhip_episode_stats(gymhip_engine* h, double* host_out, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(reduce_episode_kernel, dim3(1), dim3(kBlock), 0, s, h->at<double>(h->L.ep_partials), h->grid, (const double*)nullptr, h->at<double>(h->L.ep_totals));
+    HIP_TRY(hipGetLastError());
+    if (host_out) {
+        HIP_TRY(hipMemcpyAsync(host_out, h->at<double>(h->L.ep_totals), 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return GYMHIP_OK;
+}
+
+int gymhip_poll_error(gymhip_engine* h, int32_t* host_out, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (!host_out) return fail(GYMHIP_EINVAL, "host_out is null");
+    HIP_TRY(hipMemcpyAsync(host_out, h->at<int32_t>(h->L.error_flag), 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return GYMHIP_OK;
+}
+
+int gymhip_get_norm_stats(gymhip_engine* h, float* host_out, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->norm || !host_out) return fail(GYMHIP_EINVAL, "engine has no normaliser or host_out is null");
+    HIP_TRY(hipMemcpyAsync(host_out, h->stats_slot_ptr(h->stats_slot), (2 * h->F + 4) * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return GYMHIP_OK;
+}
+
+int gymhip_set_norm_stats(gymhip_engine* h, const float* host_in, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->norm || !host_in) return fail(GYMHIP_EINVAL, "engine has no normaliser or host_in is null");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    for (int s = 0; s < 3; s++) HIP_TRY(hipMemcpy(h->stats_slot_ptr(s), host_in, (2 * h->F + 4) * 4, hipMemcpyHostToDevice));
+    return GYMHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+// gymhip_internal.h — kernel parameter blocks shared by the engine's translation units (not part of the C ABI).
+#pragma once
+#include <cstdint>
+#include <string>
+
+namespace gymhip {
+
+extern thread_local std::string g_last_error;
+int fail(int code, const char* fmt, ...);
+
+// Per-env device arrays (N = n_envs, F = obs_dim).  See include/gymhip.h gymhip_buffers for meanings.
+struct StepBuffers {
+    void* state;             // LOCKSTEP: double2 planes [F/2][N]; F32: == obs
+    float* obs;              // f32 [N][F]
+    float* reward;           // f32 [N]
+    float* done;             // f32 [N]
+    uint8_t* truncated;      // u8  [N]
+    int32_t* elapsed;        // i32 [N]
+    int32_t* episode_index;  // i32 [N]
+    float* last_ep_return;   // f32 [N]
+    int32_t* last_ep_length; // i32 [N]
+    float* returns;          // f32 [N] or null
+};
+
+struct StepParams {
+    int64_t n;
+    int64_t env_offset;
+    uint64_t seed;
+    const void* actions;
+    const float* tape;       // f32 [tape_episodes][N][4]
+    int64_t tape_episodes;
+    const float* stats_cur;  // running statistics (shift for the batch-moment partials) or null
+    double* partials;        // [grid][16]
+    double* ep_partials;     // [grid][4] cumulative episodes / sum return / sum length
+    int32_t* error_flag;
+    uint32_t wrappers;
+    int32_t max_episode_steps;
+    int32_t reset_mode;
+    float gamma;
+    StepBuffers buf;
+};
+
+struct NormParams {
+    int64_t n;
+    const float* stats_cur;
+    float* stats_next;
+    float* stats_public;
+    const double* moments;
+    double* ep_totals_global;
+    const float* obs;
+    float* obs_norm;
+    float* reward;
+    float clip_obs, clip_reward, epsilon;
+    bool norm_obs, norm_reward, update_obs, update_ret;
+};
+
+}  // namespace gymhip

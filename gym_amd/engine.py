@@ -1,0 +1,183 @@
+"""Thin Python owner of a gymhip engine handle.
+
+torch is plumbing here: it owns the device workspace (so results are zero-copy torch tensors on the caller's
+stream) and provides torch.distributed for the one collective.  All compute runs in libgymhip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+@dataclass
+class EngineConfig:
+    env_kind: int = L.ENV_CARTPOLE
+    n_envs: int = 1
+    precision: int = L.PRECISION_LOCKSTEP_F64
+    reset_mode: int = L.RESET_TAPE
+    wrappers: int = 0
+    max_episode_steps: int = 0
+    env_offset: int = 0
+    seed: int = 0
+    clip_obs: float = 10.0      # vec_normalize.h:24-27
+    clip_reward: float = 10.0
+    gamma: float = 0.99
+    epsilon: float = 1e-8
+
+    def to_c(self) -> L.Config:
+        c = L.Config()
+        c.struct_size = C.sizeof(L.Config)
+        c.env_kind, c.precision, c.reset_mode = self.env_kind, self.precision, self.reset_mode
+        c.wrappers, c.max_episode_steps = self.wrappers, self.max_episode_steps
+        c.n_envs, c.env_offset, c.seed = self.n_envs, self.env_offset, self.seed
+        c.clip_obs, c.clip_reward, c.gamma, c.epsilon = self.clip_obs, self.clip_reward, self.gamma, self.epsilon
+        return c
+
+
+_ACT_DTYPES = {torch.int32: L.ACT_I32, torch.int64: L.ACT_I64, torch.uint8: L.ACT_U8}
+
+
+class Engine:
+    """Owns one gymhip_engine on `device`; exposes its device buffers as torch tensors (views of the workspace)."""
+
+    def __init__(self, cfg: EngineConfig, device: int | torch.device = 0):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.GymhipError("no GPU visible: the gymhip engine has no CPU fallback")
+        self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
+        self.cfg = cfg
+        ccfg = cfg.to_c()
+        nbytes = self.lib.gymhip_workspace_bytes(C.byref(ccfg))
+        if nbytes == 0:
+            raise L.GymhipError("invalid engine configuration")
+        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        base = self.workspace.data_ptr()
+        self._ws_off = (-base) % 256
+        h = C.c_void_p()
+        L.check(self.lib.gymhip_create(C.byref(ccfg), self.device.index, C.c_void_p(base + self._ws_off), nbytes, C.byref(h)), "gymhip_create")
+        self.h = h
+        b = L.Buffers()
+        L.check(self.lib.gymhip_get_buffers(self.h, C.byref(b)), "gymhip_get_buffers")
+        self.F = b.obs_dim
+        self.moments_len = b.moments_len
+        n, F = cfg.n_envs, self.F
+        self._b = b
+        self.obs = self._view(b.obs, torch.float32, (n, F))
+        self.obs_norm = self._view(b.obs_norm, torch.float32, (n, F))
+        self.reward = self._view(b.reward, torch.float32, (n,))
+        self.done = self._view(b.done, torch.float32, (n,))
+        self.truncated = self._view(b.truncated, torch.uint8, (n,))
+        self.elapsed_steps = self._view(b.elapsed_steps, torch.int32, (n,))
+        self.episode_index = self._view(b.episode_index, torch.int32, (n,))
+        self.last_episode_return = self._view(b.last_episode_return, torch.float32, (n,))
+        self.last_episode_length = self._view(b.last_episode_length, torch.int32, (n,))
+        self.returns = self._view(b.returns, torch.float32, (n,))
+        self.norm_stats = self._view(b.norm_stats, torch.float32, (2 * F + 4,))
+        self.moments = self._view(b.moments, torch.float64, (self.moments_len,))
+        self.episode_totals = self._view(b.episode_totals, torch.float64, (3,))
+        if cfg.precision == L.PRECISION_LOCKSTEP_F64:
+            self.state64 = self._view(b.state, torch.float64, (F // 2, n, 2))   # double2 planes
+        else:
+            self.state64 = None
+
+    def _view(self, ptr, dtype, shape):
+        if not ptr:
+            return None
+        off = ptr - self.workspace.data_ptr()
+        numel = int(np.prod(shape))
+        esz = torch.empty((), dtype=dtype).element_size()
+        return self.workspace[off:off + numel * esz].view(dtype).view(*shape)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gymhip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reset tape -----------------------------------------------------------------------------------
+    def upload_reset_tape(self, tape: np.ndarray):
+        tape = np.ascontiguousarray(tape, dtype=np.float32)
+        assert tape.ndim == 3 and tape.shape[1:] == (self.cfg.n_envs, 4), tape.shape
+        L.check(self.lib.gymhip_upload_reset_tape(self.h, tape.ctypes.data_as(C.c_void_p), tape.shape[0]), "gymhip_upload_reset_tape")
+
+    def generate_reset_tape(self, episodes: int):
+        L.check(self.lib.gymhip_generate_reset_tape(self.h, episodes, self._stream()), "gymhip_generate_reset_tape")
+
+    def download_reset_tape(self, episodes: int) -> np.ndarray:
+        out = np.empty((episodes, self.cfg.n_envs, 4), np.float32)
+        L.check(self.lib.gymhip_download_reset_tape(self.h, out.ctypes.data_as(C.c_void_p), episodes), "gymhip_download_reset_tape")
+        return out
+
+    def seed(self, seed: int):
+        L.check(self.lib.gymhip_seed(self.h, seed), "gymhip_seed")
+
+    # ---- stepping -------------------------------------------------------------------------------------
+    def _act(self, actions: torch.Tensor):
+        if actions.device != self.device or actions.dtype not in _ACT_DTYPES or not actions.is_contiguous() or actions.numel() != self.cfg.n_envs:
+            # TensorAdapter::decode semantics (tensor_adapter.cpp:22-23): any tensor is narrowed to int32
+            actions = actions.to(device=self.device, dtype=torch.int32).contiguous().view(-1)
+            if actions.numel() != self.cfg.n_envs:
+                raise ValueError(f"expected {self.cfg.n_envs} actions, got {actions.numel()}")
+        return actions
+
+    def reset(self):
+        L.check(self.lib.gymhip_reset(self.h, self._stream()), "gymhip_reset")
+
+    def step(self, actions: torch.Tensor):
+        a = self._act(actions)
+        L.check(self.lib.gymhip_step(self.h, C.c_void_p(a.data_ptr()), _ACT_DTYPES[a.dtype], self._stream()), "gymhip_step")
+
+    def reset_begin(self):
+        L.check(self.lib.gymhip_reset_begin(self.h, self._stream()), "gymhip_reset_begin")
+
+    def reset_finish(self):
+        L.check(self.lib.gymhip_reset_finish(self.h, self._stream()), "gymhip_reset_finish")
+
+    def step_begin(self, actions: torch.Tensor):
+        a = self._act(actions)
+        self._keep = a
+        L.check(self.lib.gymhip_step_begin(self.h, C.c_void_p(a.data_ptr()), _ACT_DTYPES[a.dtype], self._stream()), "gymhip_step_begin")
+
+    def step_finish(self):
+        L.check(self.lib.gymhip_step_finish(self.h, self._stream()), "gymhip_step_finish")
+
+    def rollout(self, action_tape: torch.Tensor, rec_done=None, rec_reward=None, rec_truncated=None, rec_obs=None):
+        assert action_tape.dtype == torch.uint8 and action_tape.is_contiguous() and action_tape.device == self.device
+        k = action_tape.shape[0]
+        assert action_tape.numel() == k * self.cfg.n_envs
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        L.check(self.lib.gymhip_rollout(self.h, ptr(action_tape), k, ptr(rec_done), ptr(rec_reward), ptr(rec_truncated), ptr(rec_obs), self._stream()), "gymhip_rollout")
+
+    # ---- statistics -----------------------------------------------------------------------------------
+    def episode_stats(self) -> np.ndarray:
+        out = np.zeros(3, np.float64)
+        L.check(self.lib.gymhip_episode_stats(self.h, out.ctypes.data_as(C.c_void_p), self._stream()), "gymhip_episode_stats")
+        return out
+
+    def poll_error(self) -> int:
+        v = C.c_int32(0)
+        L.check(self.lib.gymhip_poll_error(self.h, C.byref(v), self._stream()), "gymhip_poll_error")
+        return v.value
+
+    def get_norm_stats(self) -> np.ndarray:
+        out = np.zeros(2 * self.F + 4, np.float32)
+        L.check(self.lib.gymhip_get_norm_stats(self.h, out.ctypes.data_as(C.c_void_p), self._stream()), "gymhip_get_norm_stats")
+        return out
+
+    def set_norm_stats(self, stats: np.ndarray):
+        stats = np.ascontiguousarray(stats, np.float32)
+        assert stats.size == 2 * self.F + 4
+        L.check(self.lib.gymhip_set_norm_stats(self.h, stats.ctypes.data_as(C.c_void_p), self._stream()), "gymhip_set_norm_stats")

@@ -1,0 +1,139 @@
+/* gymhip.h — C ABI of the MI355X batched environment engine (libgymhip.so).
+ *
+ * The reference (ava6969/gym) has no FFI: its boundary is the in-process C++ class templates gym::VecEnv<dict>
+ * and its wrappers.  This ABI is what a maintainer's gym::VecEnv<false> subclass binds instead of running the
+ * serial SyncVecEnv loop (see INTEGRATION.md for that subclass; a ready one ships in
+ * gym_amd/include/gym/hip_vec_env.h).  Every entry point cites the reference interface it replaces.
+ *
+ * Conventions: plain pointers and sizes only; int status returns (0 == GYMHIP_OK), never throws across the ABI;
+ * gymhip_last_error() gives the thread-local message of the last failing call.  `stream` is a hipStream_t passed as
+ * void* (NULL = the device's default stream); all work is enqueued, nothing synchronises unless documented.
+ * Device buffers are owned by the engine (or by the caller-provided workspace) and stay valid until
+ * gymhip_destroy(); they are OVERWRITTEN by the next step — the reference returns fresh tensors every step
+ * (sync_env.h:107-112), so callers that keep a result across steps must copy it.
+ */
+#ifndef GYMHIP_H
+#define GYMHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gymhip_engine gymhip_engine;
+
+enum { GYMHIP_OK = 0, GYMHIP_EINVAL = 1, GYMHIP_EHIP = 2, GYMHIP_ESTATE = 3, GYMHIP_ETAPE = 4 };
+
+/* classic_control/cartpole.{h,cpp}, classic_control/mountain_car.{h,cpp} */
+enum { GYMHIP_ENV_CARTPOLE = 0, GYMHIP_ENV_MOUNTAINCAR = 1 };
+/* LOCKSTEP_F64: the reference's exact op sequence and precisions (double state, float where it narrows) — bit-exact
+ * streams.  F32: float state == the observation buffer, one 16-B read-modify-write per env (throughput mode). */
+enum { GYMHIP_PRECISION_LOCKSTEP_F64 = 0, GYMHIP_PRECISION_F32 = 1 };
+/* TAPE: k-th reset of env i reads tape[k][i][0..3] (host-drawn std::mt19937, cartpole.cpp:19-31).
+ * COUNTER_RNG: stateless hash(seed, global env, episode) with the same float distribution arithmetic. */
+enum { GYMHIP_RESET_TAPE = 0, GYMHIP_RESET_COUNTER_RNG = 1 };
+/* wrappers/time_limit.h, wrappers/clip_reward.h, wrappers/monitor.h, wrappers/vec_env/vec_normalize.h */
+enum {
+    GYMHIP_WRAP_TIME_LIMIT = 1u,
+    GYMHIP_WRAP_CLIP_REWARD = 2u,
+    GYMHIP_WRAP_MONITOR = 4u,
+    GYMHIP_WRAP_NORM_OBS = 8u,
+    GYMHIP_WRAP_NORM_REWARD = 16u,
+    GYMHIP_WRAP_NORM_TRAINING = 32u /* isTraining: update running stats every reset/step */
+};
+enum { GYMHIP_ACT_I32 = 0, GYMHIP_ACT_I64 = 1, GYMHIP_ACT_U8 = 2 };
+
+typedef struct gymhip_config {
+    int32_t struct_size;        /* = sizeof(gymhip_config) */
+    int32_t env_kind;
+    int32_t precision;
+    int32_t reset_mode;
+    uint32_t wrappers;          /* GYMHIP_WRAP_* bitmask */
+    int32_t max_episode_steps;  /* TimeLimit(max_episode_steps), time_limit.h:22-26 */
+    int64_t n_envs;             /* envs resident on this GPU */
+    int64_t env_offset;         /* global index of local env 0: env i is seeded seed + env_offset + i (sync_env.h:74-83) */
+    uint64_t seed;
+    float clip_obs, clip_reward, gamma, epsilon; /* vec_normalize.h:24-27 defaults 10, 10, 0.99, 1e-8 */
+} gymhip_config;
+
+/* Device pointers (NULL when the configuration has no such buffer).  N = n_envs, F = obs_dim. */
+typedef struct gymhip_buffers {
+    int32_t obs_dim;
+    int32_t moments_len;            /* doubles in `moments` */
+    void* state;                    /* LOCKSTEP: double2 planes [F/2][N]; F32: same memory as obs */
+    float* obs;                     /* f32 [N][F] raw observation after auto-reset (VecNormalize::oldObs) */
+    float* obs_norm;                /* f32 [N][F] normalised observation (NORM_OBS) */
+    float* reward;                  /* f32 [N]  (normalised in place when NORM_REWARD) */
+    float* done;                    /* f32 [N]  0/1 — the reference's done tensor is float32 (sync_env.h:102,110) */
+    uint8_t* truncated;             /* u8 [N], valid where done != 0: info["TimeLimit.truncated"] (time_limit.h:32) */
+    int32_t* elapsed_steps;         /* i32 [N] steps since the env's last reset */
+    int32_t* episode_index;         /* i32 [N] resets consumed so far (next tape row) */
+    float* last_episode_return;     /* f32 [N], valid where done != 0: info["episode"].r (monitor.h:86,97) */
+    int32_t* last_episode_length;   /* i32 [N], valid where done != 0: info["episode"].l */
+    float* returns;                 /* f32 [N] discounted return lane (vec_normalize.h:131-132,175) */
+    float* norm_stats;              /* f32 [2F+4]: obs mean[F], obs var[F], obs count, ret mean, ret var, ret count */
+    double* moments;                /* f64 [moments_len] all-reduce payload of the step in flight */
+    double* episode_totals;         /* f64 [3] cumulative episodes, sum of returns, sum of lengths (after gymhip_episode_stats) */
+} gymhip_buffers;
+
+const char* gymhip_last_error(void);
+int gymhip_version(void);
+
+/* Bytes of device workspace an engine with this configuration needs (0 on invalid config). */
+size_t gymhip_workspace_bytes(const gymhip_config* cfg);
+
+/* Replaces constructing N env objects + SyncVecEnv (sync_env.h:25-60) [+ VecNormalize (vec_normalize.h:23-59)].
+ * `workspace` may be NULL (the engine hipMallocs) or a caller-owned device allocation of at least
+ * gymhip_workspace_bytes(cfg) bytes, 256-B aligned (e.g. a torch uint8 tensor). */
+int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t workspace_bytes, gymhip_engine** out);
+int gymhip_destroy(gymhip_engine* h);
+int gymhip_get_buffers(gymhip_engine* h, gymhip_buffers* out);
+
+/* VecEnv::seed (base.h:74, sync_env.h:74-83): env i <- seed + env_offset + i.  Affects COUNTER_RNG resets; in TAPE
+ * mode the tape itself carries the seed (draw it with the same rule). */
+int gymhip_seed(gymhip_engine* h, uint64_t seed);
+
+/* Host-drawn reset tape f32 [episodes][n_envs][4] (CartPole; cartpole.cpp:19-31 + env.h:60-68 semantics), copied to the
+ * device.  MountainCar resets are deterministic (mountain_car.cpp:38-42) and need no tape. */
+int gymhip_upload_reset_tape(gymhip_engine* h, const float* host_tape, int64_t episodes);
+/* Fill a device-resident tape of `episodes` rows with the COUNTER_RNG generator (bench / throughput set-up). */
+int gymhip_generate_reset_tape(gymhip_engine* h, int64_t episodes, void* stream);
+/* Copy the device tape back (tests: lets the CPU oracle replay a device-generated tape). */
+int gymhip_download_reset_tape(gymhip_engine* h, float* host_tape, int64_t episodes);
+
+/* VecEnv::reset() (base.h:52; sync_env.h:66-72; vec_normalize.h:145-157). */
+int gymhip_reset(gymhip_engine* h, void* stream);
+/* VecEnv::step(actions) = stepAsync + stepWait (base.h:56-63; sync_env.h:85-123; vec_normalize.h:159-177).
+ * `actions` is a device array of n_envs elements of `action_dtype` (the reference narrows any tensor to int32,
+ * tensor_adapter.cpp:22-23).  gymhip_step == gymhip_step_begin + gymhip_step_finish. */
+int gymhip_step(gymhip_engine* h, const void* actions, int action_dtype, void* stream);
+/* Split form for sharded runs with the normaliser on: after _begin the `moments` buffer holds this rank's batch
+ * moments + episode statistics; the caller all-reduces (sum) it over ranks (RCCL) on `stream`, then calls _finish,
+ * which applies RunningMeanStd::updateFromMoment (running_mean_std.h:46-66) and normalises.  The same split exists
+ * for reset. */
+int gymhip_step_begin(gymhip_engine* h, const void* actions, int action_dtype, void* stream);
+int gymhip_step_finish(gymhip_engine* h, void* stream);
+int gymhip_reset_begin(gymhip_engine* h, void* stream);
+int gymhip_reset_finish(gymhip_engine* h, void* stream);
+
+/* K steps in ONE launch from a device action tape u8 [K][n_envs]; state stays in registers between steps.
+ * Optional per-step records (device, may be NULL): done u8 [K][N], reward f32 [K][N], truncated u8 [K][N],
+ * obs f32 [K][N][F].  Not available with the normaliser (it needs a grid-wide reduction per step).
+ * No reference counterpart: it is the harness form of calling VecEnv::step K times (test/classic_control.cpp:92-96). */
+int gymhip_rollout(gymhip_engine* h, const uint8_t* action_tape, int64_t k_steps, uint8_t* rec_done, float* rec_reward,
+                   uint8_t* rec_truncated, float* rec_obs, void* stream);
+
+/* Reduce the per-block episode counters into episode_totals (device) and, if `host_out` is non-NULL, copy the three
+ * doubles back (synchronises `stream`).  Monitor getters monitor.h:104-107 in aggregate form. */
+int gymhip_episode_stats(gymhip_engine* h, double* host_out, void* stream);
+/* Sticky device error word: bit0 = reset tape exhausted (an env needed more episodes than were uploaded). */
+int gymhip_poll_error(gymhip_engine* h, int32_t* host_out, void* stream);
+
+/* VecNormalize::save/load state (vec_normalize.h:79-108; running_mean_std.h:28-40) as 2F+4 floats, host side. */
+int gymhip_get_norm_stats(gymhip_engine* h, float* host_out, void* stream);
+int gymhip_set_norm_stats(gymhip_engine* h, const float* host_in, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GYMHIP_H */

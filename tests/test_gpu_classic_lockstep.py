@@ -1,0 +1,204 @@
+"""GPU parity: the HIP lockstep path vs the CPU oracle on the same host-drawn reset tape and action tape.
+
+Bar (BASELINE.json north_star): done / truncated / step-count / episode streams bit-exact; obs and reward within
+1e-5 relative (they are in fact compared exactly where noted).  All calls go through the C ABI (gym_amd._lib).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.oracle_lib import CARTPOLE, MOUNTAINCAR, F_CLIP_REWARD, F_MONITOR, F_TIME_LIMIT, splitmix_actions
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5
+
+
+def rel_err(a, b):
+    return np.abs(a - b) / np.maximum(np.abs(b), 1e-2)   # abs floor 1e-2 as in SURVEY.md §7
+
+
+def make_engine(kind, n, precision, wrappers, max_steps, reset_mode=None, seed=0, env_offset=0):
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+    cfg = EngineConfig(env_kind=kind, n_envs=n, precision=precision, reset_mode=L.RESET_TAPE if reset_mode is None else reset_mode,
+                       wrappers=wrappers, max_episode_steps=max_steps, seed=seed, env_offset=env_offset)
+    return Engine(cfg, 0)
+
+
+def test_cartpole_step_api_lockstep_every_step(oracle):
+    """N=2048 x T=1500 through gymhip_step: every output of every step compared."""
+    from gym_amd import _lib as L
+    n, T, seed = 2048, 1500, 0
+    ov = oracle.vec(CARTPOLE, n, F_TIME_LIMIT | F_MONITOR, 500)
+    ov.seed(seed)
+    tape = oracle.cartpole_reset_tape(seed, n, T // 8 + 4)
+    eng = make_engine(L.ENV_CARTPOLE, n, L.PRECISION_LOCKSTEP_F64, L.WRAP_TIME_LIMIT | L.WRAP_MONITOR, 500)
+    eng.upload_reset_tape(tape)
+    eng.reset()
+    obs0, obs0_64 = ov.reset(want64=True)
+    assert np.array_equal(eng.obs.cpu().numpy(), obs0)
+    acts = splitmix_actions(1234, T, n, 2)
+    acts_dev = torch.from_numpy(acts.astype(np.int32)).cuda()
+    n_done = 0
+    for t in range(T):
+        eng.step(acts_dev[t])
+        r = ov.step(acts[t], want64=True)
+        g_obs = eng.obs.cpu().numpy()
+        g_done = eng.done.cpu().numpy()
+        assert np.array_equal(g_done, r["done"]), f"done stream diverged at step {t}"
+        assert np.array_equal(eng.reward.cpu().numpy(), r["reward"])
+        assert rel_err(g_obs, r["obs"]).max() <= REL, f"obs diverged at step {t}"
+        d = r["done"] != 0
+        if d.any():
+            n_done += int(d.sum())
+            assert np.array_equal(eng.truncated.cpu().numpy()[d], r["truncated"][d])
+            assert np.array_equal(eng.last_episode_return.cpu().numpy()[d], r["ep_r"][d])
+            assert np.array_equal(eng.last_episode_length.cpu().numpy()[d].astype(np.float32), r["ep_l"][d])
+        if t % 250 == 0 or t == T - 1:
+            # the fp64 state itself: bit-exact unless device sin/cos round differently from glibc (then <= 1e-12)
+            st = eng.state64.cpu().numpy()                      # [2][n][2] double2 planes
+            g64 = np.concatenate([st[0], st[1]], axis=1)        # [n][4]
+            assert np.abs(g64 - r["obs64"]).max() <= 1e-12
+    assert n_done > n * T / 40            # episodes did end (mean length ~22)
+    assert eng.poll_error() == 0
+    tot = eng.episode_stats()
+    assert tot[0] == n_done
+
+
+def test_cartpole_config2_rollout_65536x10000(oracle):
+    """BASELINE config 2: N=65,536, 10^4-step trajectories, fixed action tape, lockstep vs the CPU oracle.
+    Streams (done, truncated, reward) are compared for EVERY step; obs for every step of the last chunk and at every
+    chunk boundary."""
+    from gym_amd import _lib as L
+    n, T, chunk, seed = 65536, 10000, 500, 0
+    ov = oracle.vec(CARTPOLE, n, F_TIME_LIMIT | F_MONITOR, 500)
+    ov.seed(seed)
+    eng = make_engine(L.ENV_CARTPOLE, n, L.PRECISION_LOCKSTEP_F64, L.WRAP_TIME_LIMIT | L.WRAP_MONITOR, 500)
+    eng.upload_reset_tape(oracle.cartpole_reset_tape(seed, n, T // 8 + 8))
+    eng.reset()
+    assert np.array_equal(eng.obs.cpu().numpy(), ov.reset())
+    rec_done = torch.empty((chunk, n), dtype=torch.uint8, device="cuda")
+    rec_trunc = torch.empty((chunk, n), dtype=torch.uint8, device="cuda")
+    rec_rew = torch.empty((chunk, n), dtype=torch.float32, device="cuda")
+    rec_obs = torch.empty((chunk, n, 4), dtype=torch.float32, device="cuda")
+    episodes = 0
+    for c in range(T // chunk):
+        last = c == T // chunk - 1
+        acts = splitmix_actions(1234 + c * chunk * n, chunk, n, 2)
+        eng.rollout(torch.from_numpy(acts).cuda(), rec_done, rec_rew, rec_trunc, rec_obs if last else None)
+        r = ov.rollout(acts, rec_obs=last)
+        assert np.array_equal(rec_done.cpu().numpy(), r["done"]), f"done stream diverged in chunk {c}"
+        assert np.array_equal(rec_trunc.cpu().numpy(), r["truncated"]), f"truncated stream diverged in chunk {c}"
+        assert np.array_equal(rec_rew.cpu().numpy(), r["reward"])
+        assert rel_err(eng.obs.cpu().numpy(), r["final_obs"]).max() <= REL
+        if last:
+            assert rel_err(rec_obs.cpu().numpy(), r["obs"]).max() <= REL
+        episodes += int(r["done"].sum())
+    st = eng.state64.cpu().numpy()
+    assert np.abs(np.concatenate([st[0], st[1]], axis=1) - r["final_obs64"]).max() <= 1e-12
+    assert eng.poll_error() == 0
+    assert eng.episode_stats()[0] == episodes
+
+
+def test_mountaincar_lockstep(oracle):
+    """MountainCar + TimeLimit(200) + ClipReward + Monitor, N=8192 x T=600 via gymhip_step (i64 and u8 actions)."""
+    from gym_amd import _lib as L
+    n, T = 8192, 600
+    ov = oracle.vec(MOUNTAINCAR, n, F_TIME_LIMIT | F_CLIP_REWARD | F_MONITOR, 200)
+    eng = make_engine(L.ENV_MOUNTAINCAR, n, L.PRECISION_LOCKSTEP_F64, L.WRAP_TIME_LIMIT | L.WRAP_CLIP_REWARD | L.WRAP_MONITOR, 200)
+    eng.reset()
+    assert np.array_equal(eng.obs.cpu().numpy(), ov.reset())
+    acts = splitmix_actions(77, T, n, 3)
+    a64 = torch.from_numpy(acts.astype(np.int64)).cuda()
+    a8 = torch.from_numpy(acts).cuda()
+    for t in range(T):
+        eng.step(a64[t] if t % 2 else a8[t])
+        r = ov.step(acts[t])
+        assert np.array_equal(eng.done.cpu().numpy(), r["done"]), t
+        assert np.array_equal(eng.reward.cpu().numpy(), r["reward"])
+        assert rel_err(eng.obs.cpu().numpy(), r["obs"]).max() <= REL, t
+        d = r["done"] != 0
+        if d.any():
+            assert np.array_equal(eng.truncated.cpu().numpy()[d], r["truncated"][d])
+            assert np.array_equal(eng.last_episode_length.cpu().numpy()[d].astype(np.float32), r["ep_l"][d])
+            assert np.array_equal(eng.last_episode_return.cpu().numpy()[d], r["ep_r"][d])
+    assert eng.episode_stats()[0] == 3 * n   # every episode truncates at 200 under random actions
+
+
+def test_mountaincar_goal_reached_directed_policy(oracle):
+    """Force the rare branch: an energy-pumping policy reaches the goal (done without truncation) in both paths."""
+    from gym_amd import _lib as L
+    n, T = 256, 400
+    ov = oracle.vec(MOUNTAINCAR, n, F_TIME_LIMIT | F_MONITOR, 200)
+    eng = make_engine(L.ENV_MOUNTAINCAR, n, L.PRECISION_LOCKSTEP_F64, L.WRAP_TIME_LIMIT | L.WRAP_MONITOR, 200)
+    eng.reset()
+    obs = ov.reset()
+    terminated = 0
+    for t in range(T):
+        a = np.where(obs[:, 1] >= 0, 2, 0).astype(np.int32)   # push along the velocity
+        a[: n // 4] = 1                                     # a quarter of the envs idle (they truncate)
+        eng.step(torch.from_numpy(a).cuda())
+        r = ov.step(a)
+        obs = r["obs"]
+        assert np.array_equal(eng.done.cpu().numpy(), r["done"]), t
+        d = r["done"] != 0
+        if d.any():
+            assert np.array_equal(eng.truncated.cpu().numpy()[d], r["truncated"][d])
+            terminated += int((d & (r["truncated"] == 0)).sum())
+        assert rel_err(eng.obs.cpu().numpy(), obs).max() <= REL
+    assert terminated > 0
+
+
+def test_cartpole_no_time_limit_uses_internal_500(oracle):
+    """Without TimeLimit the env's own `timeStep == 500` test (cartpole.cpp:64, pre-increment) ends the episode on the
+    501st step.  A balancing bang-bang policy keeps the pole up long enough to reach it."""
+    from gym_amd import _lib as L
+    n, T = 128, 1100
+    ov = oracle.vec(CARTPOLE, n, F_MONITOR, 0)
+    ov.seed(3)
+    eng = make_engine(L.ENV_CARTPOLE, n, L.PRECISION_LOCKSTEP_F64, L.WRAP_MONITOR, 0)
+    eng.upload_reset_tape(oracle.cartpole_reset_tape(3, n, 64))
+    eng.reset()
+    obs = ov.reset()
+    lens = []
+    for t in range(T):
+        a = (3.0 * obs[:, 2] + obs[:, 3] + 0.05 * obs[:, 0] + 0.1 * obs[:, 1] > 0).astype(np.int32)
+        eng.step(torch.from_numpy(a).cuda())
+        r = ov.step(a)
+        obs = r["obs"]
+        assert np.array_equal(eng.done.cpu().numpy(), r["done"]), t
+        d = r["done"] != 0
+        if d.any():
+            lens += list(r["ep_l"][d])
+            assert np.array_equal(eng.last_episode_length.cpu().numpy()[d].astype(np.float32), r["ep_l"][d])
+        assert rel_err(eng.obs.cpu().numpy(), obs).max() <= REL
+    assert 501.0 in lens
+
+
+def test_engine_errors():
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+    with pytest.raises(L.GymhipError):
+        Engine(EngineConfig(n_envs=0), 0)
+    eng = Engine(EngineConfig(env_kind=L.ENV_CARTPOLE, n_envs=64), 0)
+    with pytest.raises(L.GymhipError, match="no reset tape"):
+        eng.reset()
+    eng2 = Engine(EngineConfig(env_kind=L.ENV_MOUNTAINCAR, n_envs=64), 0)
+    with pytest.raises(L.GymhipError, match="before reset"):
+        eng2.step(torch.zeros(64, dtype=torch.int32, device="cuda"))
+    with pytest.raises(ValueError):
+        eng2.reset()
+        eng2.step(torch.zeros(63, dtype=torch.int32, device="cuda"))
+
+
+def test_reset_tape_exhaustion_sets_error_flag(oracle):
+    from gym_amd import _lib as L
+    n = 256
+    eng = make_engine(L.ENV_CARTPOLE, n, L.PRECISION_LOCKSTEP_F64, L.WRAP_TIME_LIMIT, 500)
+    eng.upload_reset_tape(oracle.cartpole_reset_tape(0, n, 2))
+    eng.reset()
+    a = torch.ones(n, dtype=torch.int32, device="cuda")
+    for _ in range(60):
+        eng.step(a)
+    assert eng.poll_error() & 1
