@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=16 * 1024 * 1024)
     ap.add_argument("--env", default="cartpole", choices=["cartpole", "mountaincar"])
     ap.add_argument("--mode", default="lockstep", choices=["lockstep", "f32"])
+    ap.add_argument("--reset-mode", default="tape", choices=["tape", "rng"], help="CartPole reset source (tape = lockstep-faithful)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (f32 / MountainCar) measurements")
@@ -116,10 +117,10 @@ def main():
         kind = L.ENV_CARTPOLE if env == "cartpole" else L.ENV_MOUNTAINCAR
         wrappers = L.WRAP_TIME_LIMIT | L.WRAP_MONITOR | (L.WRAP_CLIP_REWARD if env == "mountaincar" else 0)
         cfg = EngineConfig(env_kind=kind, n_envs=n, precision=L.PRECISION_LOCKSTEP_F64 if mode == "lockstep" else L.PRECISION_F32,
-                           reset_mode=L.RESET_TAPE if env == "cartpole" else L.RESET_COUNTER_RNG, wrappers=wrappers,
+                           reset_mode=L.RESET_TAPE if (env == "cartpole" and args.reset_mode == "tape") else L.RESET_COUNTER_RNG, wrappers=wrappers,
                            max_episode_steps=500 if env == "cartpole" else 200, env_offset=rank * n, seed=0)
         eng = Engine(cfg, local_rank)
-        if env == "cartpole":
+        if env == "cartpole" and args.reset_mode == "tape":
             # reset tape rows: every episode lasts >= 8 steps, so (W+K)/8 + 2 rows can never run out
             eng.generate_reset_tape((args.steps + args.warmup) // 8 + 2)
         eng.reset()

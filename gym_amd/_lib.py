@@ -50,11 +50,7 @@ class Buffers(C.Structure):
         ("obs_norm", C.c_void_p),
         ("reward", C.c_void_p),
         ("done", C.c_void_p),
-        ("truncated", C.c_void_p),
-        ("elapsed_steps", C.c_void_p),
-        ("episode_index", C.c_void_p),
-        ("last_episode_return", C.c_void_p),
-        ("last_episode_length", C.c_void_p),
+        ("counter", C.c_void_p),
         ("returns", C.c_void_p),
         ("norm_stats", C.c_void_p),
         ("moments", C.c_void_p),
@@ -95,6 +91,7 @@ SIGNATURES = {
     "gymhip_reset_begin": (C.c_int, [_vp, _vp]),
     "gymhip_reset_finish": (C.c_int, [_vp, _vp]),
     "gymhip_rollout": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gymhip_decode_counters": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gymhip_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_poll_error": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_get_norm_stats": (C.c_int, [_vp, _vp, _vp]),

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -155,6 +156,28 @@ __device__ inline bool mountaincar_step(float (&s)[2], int action) {
     return pos >= 0.5f;
 }
 
+// Packed per-env counter word (u32, one per env, rewritten every step — see gymhip.h `counter`):
+//   bit 31      the LAST step finished an episode (the env was auto-reset)
+//   bit 30      that episode was truncated by TimeLimit
+//   bits S..29  reset-tape cursor = tape rows consumed so far (TAPE mode, CartPole only), else 0
+//   bits 0..S-1 steps: the finished episode's length if bit 31 is set, else steps since the last reset
+// S = 10 for CartPole (an episode never exceeds 501 steps, cartpole.cpp:64), 30 for MountainCar (no tape, no cursor).
+template <int KIND> struct CounterWord {
+    static constexpr int S = KIND == GYMHIP_ENV_CARTPOLE ? GYMHIP_COUNTER_STEP_BITS_CARTPOLE : GYMHIP_COUNTER_STEP_BITS_MOUNTAINCAR;
+    static constexpr uint32_t kStepMask = (1u << S) - 1u;
+    static constexpr uint32_t kCursorMask = (1u << (30 - S)) - 1u;
+    __host__ __device__ static int steps_field(uint32_t w) { return (int)(w & kStepMask); }
+    __host__ __device__ static int steps_now(uint32_t w) { return (w >> 31) ? 0 : (int)(w & kStepMask); }
+    __host__ __device__ static uint32_t cursor(uint32_t w) { return (w >> S) & kCursorMask; }
+    __device__ static uint32_t next_cursor(uint32_t c, int32_t* error_flag) {
+        if (c >= kCursorMask) { atomicOr(error_flag, 2); return 0; }   // cursor field exhausted (2^20 episodes per env)
+        return c + 1;
+    }
+    __host__ __device__ static uint32_t pack(int t, uint32_t cur, bool done, bool trunc) {
+        return (done ? 0x80000000u : 0u) | (trunc ? 0x40000000u : 0u) | (cur << S) | (uint32_t)t;
+    }
+};
+
 template <int KIND> struct EnvTraits;
 template <> struct EnvTraits<KIND_CARTPOLE> { static constexpr int F = 4; static constexpr float step_reward = 1.0f; };
 template <> struct EnvTraits<KIND_MOUNTAINCAR> { static constexpr int F = 2; static constexpr float step_reward = -1.0f; };
@@ -248,14 +271,16 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
     const StepBuffers& b = p.buf;
     const bool time_limit = p.wrappers & GYMHIP_WRAP_TIME_LIMIT;
     const bool clip = p.wrappers & GYMHIP_WRAP_CLIP_REWARD;
-    const bool monitor = p.wrappers & GYMHIP_WRAP_MONITOR;
+    const bool tape_mode = KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE;
     const bool ret_lane = (p.wrappers & GYMHIP_WRAP_NORM_REWARD) && (p.wrappers & GYMHIP_WRAP_NORM_TRAINING);
 
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * kBlock) {
         T s[F];
         if constexpr (LOCKSTEP) load_state<F>(b, p.n, i, s); else load_obs(b.obs, i, s);
         const int action = (int)actions[i];
-        int t = b.elapsed[i];
+        const uint32_t w = b.counter[i];       // packed step counter / episode record / tape cursor (gymhip.h)
+        int t = CounterWord<KIND>::steps_now(w);
+        uint32_t cursor = CounterWord<KIND>::cursor(w);
 
         bool env_done;
         if constexpr (KIND == KIND_CARTPOLE) env_done = cartpole_step(s, action, t); else env_done = mountaincar_step(s, action);
@@ -264,23 +289,22 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
         if (time_limit && t >= p.max_episode_steps) { trunc = !env_done; done = true; }   // time_limit.h:30-34
         float reward = EnvTraits<KIND>::step_reward;
         if (clip) reward = reward == 0.f ? reward : (reward > 0.f ? 1.f : -1.f);           // clip_reward.h:22-24
-        (void)clip;
 
         if (done) {
             // Monitor (monitor.h:78-97): every step of these envs pays the same reward, so the ordered float sum of
-            // t copies equals float(t)*reward exactly (t < 2^24).
-            const float ep_ret = (float)t * reward;
-            if (monitor) { b.last_ep_return[i] = ep_ret; b.last_ep_length[i] = t; }
-            b.truncated[i] = trunc ? 1 : 0;
-            ep[0] += 1.0; ep[1] += (double)ep_ret; ep[2] += (double)t;
-            int64_t e = b.episode_index[i];
-            b.episode_index[i] = (int32_t)(e + 1);
-            if (KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE && e >= p.tape_episodes) {
-                atomicOr(p.error_flag, 1);
-                e = e % p.tape_episodes;
+            // t copies equals float(t)*reward exactly (t < 2^24).  The finished episode's (length, truncated) and the
+            // reset-tape cursor live in the counter word, which is rewritten every step anyway: no extra HBM traffic
+            // and no scattered read-modify-write on the done path.
+            ep[0] += 1.0; ep[1] += (double)((float)t * reward); ep[2] += (double)t;
+            int64_t e;
+            if (tape_mode) {
+                e = cursor;
+                if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
+                cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
+            } else {
+                e = p.step_counter;            // stateless: (seed, env, global step) is unique per reset
             }
             reset_state<KIND, T>(p, i, e, s);   // sync_env.h:92-100: terminal obs replaced by the reset obs
-            t = 0;
         }
 
         float o[F];
@@ -288,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
         for (int f = 0; f < F; f++) o[f] = (float)s[f];
         if constexpr (LOCKSTEP) store_state<F>(b, p.n, i, s);
         store_obs(b.obs, i, o);
-        b.elapsed[i] = t;
+        b.counter[i] = CounterWord<KIND>::pack(t, cursor, done, trunc);
         b.reward[i] = reward;
         b.done[i] = done ? 1.f : 0.f;
 
@@ -332,19 +356,15 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepParams p) {
     const StepBuffers& b = p.buf;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * kBlock) {
         T s[F];
-        reset_state<KIND, T>(p, i, 0, s);
+        reset_state<KIND, T>(p, i, p.reset_mode == GYMHIP_RESET_TAPE ? 0 : p.step_counter, s);
         float o[F];
 #pragma unroll
         for (int f = 0; f < F; f++) o[f] = (float)s[f];
         if constexpr (LOCKSTEP) store_state<F>(b, p.n, i, s);
         store_obs(b.obs, i, o);
-        b.elapsed[i] = 0;
-        b.episode_index[i] = 1;
+        b.counter[i] = CounterWord<KIND>::pack(0, (KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE) ? 1u : 0u, false, false);
         b.reward[i] = 0.f;
         b.done[i] = 0.f;
-        b.truncated[i] = 0;
-        b.last_ep_return[i] = 0.f;
-        b.last_ep_length[i] = 0;
         if (b.returns) b.returns[i] = 0.f;                        // vec_normalize.h:147
         if constexpr (NORM) {
 #pragma unroll
@@ -455,14 +475,15 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepParams p, con
     const StepBuffers& b = p.buf;
     const bool time_limit = p.wrappers & GYMHIP_WRAP_TIME_LIMIT;
     const bool clip = p.wrappers & GYMHIP_WRAP_CLIP_REWARD;
-    const bool monitor = p.wrappers & GYMHIP_WRAP_MONITOR;
+    const bool tape_mode = KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE;
     double ep[3] = {0.0, 0.0, 0.0};
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * kBlock) {
         T s[F];
         if constexpr (LOCKSTEP) load_state<F>(b, p.n, i, s); else load_obs(b.obs, i, s);
-        int t = b.elapsed[i];
-        int64_t e = b.episode_index[i];
-        float reward = 0.f; bool done = false; bool any_done = false; bool last_trunc = false; float last_ret = 0.f; int last_len = 0;
+        const uint32_t w = b.counter[i];
+        int t = CounterWord<KIND>::steps_now(w);
+        uint32_t cursor = CounterWord<KIND>::cursor(w);
+        float reward = 0.f; bool done = false; uint32_t rec = w;
         for (int64_t k = 0; k < K; k++) {
             const int action = (int)tape[k * p.n + i];
             bool env_done;
@@ -473,13 +494,19 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepParams p, con
             reward = EnvTraits<KIND>::step_reward;
             if (clip) reward = reward == 0.f ? reward : (reward > 0.f ? 1.f : -1.f);
             if (done) {
-                last_ret = (float)t * reward; last_len = t; last_trunc = trunc; any_done = true;
-                ep[0] += 1.0; ep[1] += (double)last_ret; ep[2] += (double)t;
-                int64_t er = e;
-                if (KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE && er >= p.tape_episodes) { atomicOr(p.error_flag, 1); er = er % p.tape_episodes; }
+                ep[0] += 1.0; ep[1] += (double)((float)t * reward); ep[2] += (double)t;
+                int64_t er;
+                if (tape_mode) {
+                    er = cursor;
+                    if (er >= p.tape_episodes) { atomicOr(p.error_flag, 1); er = er % p.tape_episodes; }
+                    cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
+                } else {
+                    er = p.step_counter + k;
+                }
                 reset_state<KIND, T>(p, i, er, s);
-                e += 1; t = 0;
             }
+            rec = CounterWord<KIND>::pack(t, cursor, done, trunc);
+            if (done) t = 0;
             if (rec_done) rec_done[k * p.n + i] = done;
             if (rec_reward) rec_reward[k * p.n + i] = reward;
             if (rec_trunc) rec_trunc[k * p.n + i] = trunc;
@@ -495,14 +522,9 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepParams p, con
         for (int f = 0; f < F; f++) o[f] = (float)s[f];
         if constexpr (LOCKSTEP) store_state<F>(b, p.n, i, s);
         store_obs(b.obs, i, o);
-        b.elapsed[i] = t;
-        b.episode_index[i] = (int32_t)e;
+        b.counter[i] = rec;
         b.reward[i] = reward;
         b.done[i] = done ? 1.f : 0.f;
-        if (any_done) {   // "valid where done" lanes describe the env's most recent finished episode
-            b.truncated[i] = last_trunc;
-            if (monitor) { b.last_ep_return[i] = last_ret; b.last_ep_length[i] = last_len; }
-        }
     }
     block_reduce_store<3>(ep, p.ep_partials + (int64_t)blockIdx.x * 4, true);
 }
@@ -521,6 +543,22 @@ __global__ __launch_bounds__(kBlock) void reduce_episode_kernel(const double* ep
     (void)extra;
 }
 
+// Materialise info["episode"] / info["TimeLimit.truncated"] lanes from the step-counter record words (valid where done).
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void decode_counter_kernel(const uint32_t* counter, int64_t n, int32_t* elapsed, int32_t* len,
+                                                                uint8_t* trunc, float* ret, int32_t* cursor) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const uint32_t w = counter[i];
+        const bool fin = w >> 31;
+        const int l = fin ? CounterWord<KIND>::steps_field(w) : 0;
+        if (elapsed) elapsed[i] = CounterWord<KIND>::steps_now(w);
+        if (len) len[i] = l;
+        if (trunc) trunc[i] = fin && (w & 0x40000000u) ? 1 : 0;
+        if (ret) ret[i] = (float)l * EnvTraits<KIND>::step_reward;   // ClipReward maps +-1 to itself (clip_reward.h:22-24)
+        if (cursor) cursor[i] = (int32_t)CounterWord<KIND>::cursor(w);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void fill_tape_kernel(float4* tape, int64_t n, int64_t episodes, uint64_t seed, int64_t env_offset) {
     const int64_t total = n * episodes;
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < total; j += (int64_t)gridDim.x * kBlock) {
@@ -537,7 +575,7 @@ __global__ __launch_bounds__(kBlock) void fill_tape_kernel(float4* tape, int64_t
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t state, obs, obs_norm, reward, done, truncated, elapsed, episode_index, last_ep_return, last_ep_length, returns;
+    size_t state, obs, obs_norm, reward, done, counter, returns;
     size_t stats /*3 slots*/, moments, partials, ep_partials, ep_totals, ep_totals_global, error_flag, total;
 };
 
@@ -570,11 +608,7 @@ Layout make_layout(const gymhip_config& c) {
     L.obs_norm = (c.wrappers & GYMHIP_WRAP_NORM_OBS) ? take(n * F * 4) : (size_t)-1;
     L.reward = take(n * 4);
     L.done = take(n * 4);
-    L.truncated = take(n);
-    L.elapsed = take(n * 4);
-    L.episode_index = take(n * 4);
-    L.last_ep_return = take(n * 4);
-    L.last_ep_length = take(n * 4);
+    L.counter = take(n * 4);
     L.returns = (c.wrappers & GYMHIP_WRAP_NORM_REWARD) ? take(n * 4) : (size_t)-1;
     L.stats = norm ? take(3 * 16 * 4) : (size_t)-1;
     L.moments = take(kMaxCols * 8);
@@ -605,6 +639,7 @@ struct gymhip_engine {
     bool did_reset;
     bool pending_finish;     // a *_begin with the normaliser on awaits its *_finish
     bool pending_is_reset;
+    int64_t step_counter;    // VecEnv steps taken so far (COUNTER_RNG reset key)
 
     template <typename T> T* at(size_t off) const { return off == (size_t)-1 ? nullptr : (T*)(ws + off); }
     float* stats_slot_ptr(int s) const { return at<float>(L.stats) + 16 * s; }
@@ -621,6 +656,7 @@ StepParams make_params(gymhip_engine* h) {
     p.max_episode_steps = h->cfg.max_episode_steps;
     p.reset_mode = h->cfg.reset_mode;
     p.gamma = h->cfg.gamma;
+    p.step_counter = h->step_counter;
     p.tape = h->tape;
     p.tape_episodes = h->tape_episodes;
     p.error_flag = h->at<int32_t>(h->L.error_flag);
@@ -632,11 +668,7 @@ StepParams make_params(gymhip_engine* h) {
     b.obs = h->at<float>(h->L.obs);
     b.reward = h->at<float>(h->L.reward);
     b.done = h->at<float>(h->L.done);
-    b.truncated = h->at<uint8_t>(h->L.truncated);
-    b.elapsed = h->at<int32_t>(h->L.elapsed);
-    b.episode_index = h->at<int32_t>(h->L.episode_index);
-    b.last_ep_return = h->at<float>(h->L.last_ep_return);
-    b.last_ep_length = h->at<int32_t>(h->L.last_ep_length);
+    b.counter = h->at<uint32_t>(h->L.counter);
     b.returns = h->at<float>(h->L.returns);
     return p;
 }
@@ -744,6 +776,7 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
     h->stats_slot = 0;
     h->tape = nullptr; h->tape_episodes = 0;
     h->did_reset = false; h->pending_finish = false; h->pending_is_reset = false;
+    h->step_counter = 0;
     if (workspace) {
         if (workspace_bytes < h->L.total || ((uintptr_t)workspace & 255)) { delete h; return fail(GYMHIP_EINVAL, "workspace too small (%zu < %zu) or not 256-B aligned", workspace_bytes, h->L.total); }
         h->ws = (char*)workspace; h->owns_ws = false;
@@ -787,11 +820,7 @@ int gymhip_get_buffers(gymhip_engine* h, gymhip_buffers* out) {
     out->obs_norm = h->at<float>(h->L.obs_norm);
     out->reward = h->at<float>(h->L.reward);
     out->done = h->at<float>(h->L.done);
-    out->truncated = h->at<uint8_t>(h->L.truncated);
-    out->elapsed_steps = h->at<int32_t>(h->L.elapsed);
-    out->episode_index = h->at<int32_t>(h->L.episode_index);
-    out->last_episode_return = h->at<float>(h->L.last_ep_return);
-    out->last_episode_length = h->at<int32_t>(h->L.last_ep_length);
+    out->counter = h->at<uint32_t>(h->L.counter);
     out->returns = h->at<float>(h->L.returns);
     out->norm_stats = h->norm ? h->stats_slot_ptr(2) : nullptr;
     out->moments = h->at<double>(h->L.moments);
@@ -852,6 +881,7 @@ int gymhip_reset_begin(gymhip_engine* h, void* stream) {
     if (h->norm) launch_reduce_partials(h, s);
     HIP_TRY(hipGetLastError());
     h->did_reset = true;
+    h->step_counter += 1;
     h->pending_finish = h->norm; h->pending_is_reset = true;
     return GYMHIP_OK;
 }
@@ -868,6 +898,7 @@ int gymhip_step_begin(gymhip_engine* h, const void* actions, int action_dtype, v
     if (h->cfg.env_kind == KIND_CARTPOLE) launch_step_kind<KIND_CARTPOLE>(h, p, action_dtype, s); else launch_step_kind<KIND_MOUNTAINCAR>(h, p, action_dtype, s);
     if (h->norm) launch_reduce_partials(h, s);
     HIP_TRY(hipGetLastError());
+    h->step_counter += 1;
     h->pending_finish = h->norm; h->pending_is_reset = false;
     return GYMHIP_OK;
 }
@@ -910,6 +941,19 @@ int gymhip_rollout(gymhip_engine* h, const uint8_t* action_tape, int64_t k_steps
         if (lock) hipLaunchKernelGGL((rollout_kernel<KIND_MOUNTAINCAR, true>), g, bdim, 0, s, p, action_tape, k_steps, rec_done, rec_reward, rec_truncated, rec_obs);
         else hipLaunchKernelGGL((rollout_kernel<KIND_MOUNTAINCAR, false>), g, bdim, 0, s, p, action_tape, k_steps, rec_done, rec_reward, rec_truncated, rec_obs);
     }
+    HIP_TRY(hipGetLastError());
+    h->step_counter += k_steps;
+    return GYMHIP_OK;
+}
+
+int gymhip_decode_counters(gymhip_engine* h, int32_t* elapsed_steps, int32_t* episode_length, uint8_t* truncated, float* episode_return,
+                           int32_t* tape_cursor, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    const uint32_t* c = h->at<uint32_t>(h->L.counter);
+    if (h->cfg.env_kind == KIND_CARTPOLE)
+        hipLaunchKernelGGL(decode_counter_kernel<KIND_CARTPOLE>, dim3(h->grid), dim3(kBlock), 0, (hipStream_t)stream, c, h->cfg.n_envs, elapsed_steps, episode_length, truncated, episode_return, tape_cursor);
+    else
+        hipLaunchKernelGGL(decode_counter_kernel<KIND_MOUNTAINCAR>, dim3(h->grid), dim3(kBlock), 0, (hipStream_t)stream, c, h->cfg.n_envs, elapsed_steps, episode_length, truncated, episode_return, tape_cursor);
     HIP_TRY(hipGetLastError());
     return GYMHIP_OK;
 }

@@ -14,11 +14,7 @@ struct StepBuffers {
     float* obs;              // f32 [N][F]
     float* reward;           // f32 [N]
     float* done;             // f32 [N]
-    uint8_t* truncated;      // u8  [N]
-    int32_t* elapsed;        // i32 [N]
-    int32_t* episode_index;  // i32 [N]
-    float* last_ep_return;   // f32 [N]
-    int32_t* last_ep_length; // i32 [N]
+    uint32_t* counter;       // u32 [N] packed step counter / finished-episode record / tape cursor (gymhip.h)
     float* returns;          // f32 [N] or null
 };
 
@@ -37,6 +33,7 @@ struct StepParams {
     int32_t max_episode_steps;
     int32_t reset_mode;
     float gamma;
+    int64_t step_counter;
     StepBuffers buf;
 };
 

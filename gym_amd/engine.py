@@ -71,11 +71,8 @@ class Engine:
         self.obs_norm = self._view(b.obs_norm, torch.float32, (n, F))
         self.reward = self._view(b.reward, torch.float32, (n,))
         self.done = self._view(b.done, torch.float32, (n,))
-        self.truncated = self._view(b.truncated, torch.uint8, (n,))
-        self.elapsed_steps = self._view(b.elapsed_steps, torch.int32, (n,))
-        self.episode_index = self._view(b.episode_index, torch.int32, (n,))
-        self.last_episode_return = self._view(b.last_episode_return, torch.float32, (n,))
-        self.last_episode_length = self._view(b.last_episode_length, torch.int32, (n,))
+        self.counter = self._view(b.counter, torch.int32, (n,))   # packed words (gymhip.h); decode with counters()
+        self._dec = None
         self.returns = self._view(b.returns, torch.float32, (n,))
         self.norm_stats = self._view(b.norm_stats, torch.float32, (2 * F + 4,))
         self.moments = self._view(b.moments, torch.float64, (self.moments_len,))
@@ -160,6 +157,24 @@ class Engine:
         assert action_tape.numel() == k * self.cfg.n_envs
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         L.check(self.lib.gymhip_rollout(self.h, ptr(action_tape), k, ptr(rec_done), ptr(rec_reward), ptr(rec_truncated), ptr(rec_obs), self._stream()), "gymhip_rollout")
+
+    def counters(self):
+        """Decode the packed counter words into device lanes: dict(elapsed i32, length i32, truncated u8, ret f32,
+        cursor i32), each [N].  length/truncated/ret describe the episode the LAST step finished (valid where
+        done != 0, zero elsewhere): info["episode"].{l,r} and info["TimeLimit.truncated"]."""
+        n = self.cfg.n_envs
+        if self._dec is None:
+            mk = lambda dt: torch.empty(n, dtype=dt, device=self.device)
+            self._dec = dict(elapsed=mk(torch.int32), length=mk(torch.int32), truncated=mk(torch.uint8), ret=mk(torch.float32), cursor=mk(torch.int32))
+        d = self._dec
+        p = lambda t: C.c_void_p(t.data_ptr())
+        L.check(self.lib.gymhip_decode_counters(self.h, p(d["elapsed"]), p(d["length"]), p(d["truncated"]), p(d["ret"]), p(d["cursor"]), self._stream()),
+                "gymhip_decode_counters")
+        return d
+
+    def episode_info(self):
+        d = self.counters()
+        return d["length"], d["truncated"], d["ret"]
 
     # ---- statistics -----------------------------------------------------------------------------------
     def episode_stats(self) -> np.ndarray:

@@ -42,6 +42,10 @@ enum {
     GYMHIP_WRAP_NORM_TRAINING = 32u /* isTraining: update running stats every reset/step */
 };
 enum { GYMHIP_ACT_I32 = 0, GYMHIP_ACT_I64 = 1, GYMHIP_ACT_U8 = 2 };
+/* Width S of the step field in the packed counter word (gymhip_buffers.counter).  A CartPole episode never exceeds
+ * 501 steps (cartpole.cpp:64); MountainCar has no reset tape, so its word carries no cursor. */
+#define GYMHIP_COUNTER_STEP_BITS_CARTPOLE 10
+#define GYMHIP_COUNTER_STEP_BITS_MOUNTAINCAR 30
 
 typedef struct gymhip_config {
     int32_t struct_size;        /* = sizeof(gymhip_config) */
@@ -65,11 +69,15 @@ typedef struct gymhip_buffers {
     float* obs_norm;                /* f32 [N][F] normalised observation (NORM_OBS) */
     float* reward;                  /* f32 [N]  (normalised in place when NORM_REWARD) */
     float* done;                    /* f32 [N]  0/1 — the reference's done tensor is float32 (sync_env.h:102,110) */
-    uint8_t* truncated;             /* u8 [N], valid where done != 0: info["TimeLimit.truncated"] (time_limit.h:32) */
-    int32_t* elapsed_steps;         /* i32 [N] steps since the env's last reset */
-    int32_t* episode_index;         /* i32 [N] resets consumed so far (next tape row) */
-    float* last_episode_return;     /* f32 [N], valid where done != 0: info["episode"].r (monitor.h:86,97) */
-    int32_t* last_episode_length;   /* i32 [N], valid where done != 0: info["episode"].l */
+    uint32_t* counter;              /* u32 [N] packed per-env bookkeeping word, rewritten by every step (so the episode
+                                       records and the tape cursor cost no HBM traffic of their own):
+                                         bit 31      the LAST step finished an episode and auto-reset the env
+                                         bit 30      that episode's info["TimeLimit.truncated"] (time_limit.h:32)
+                                         bits S..29  reset-tape rows consumed so far (TAPE mode), else 0
+                                         bits 0..S-1 bit 31 set: the finished episode's length (info["episode"].l,
+                                                     monitor.h:86); clear: steps since the last reset
+                                                     (TimeLimit::elapsedSteps == Monitor::_steps == CartPole timeStep)
+                                       S = GYMHIP_COUNTER_STEP_BITS_<ENV>.  gymhip_decode_counters() expands it. */
     float* returns;                 /* f32 [N] discounted return lane (vec_normalize.h:131-132,175) */
     float* norm_stats;              /* f32 [2F+4]: obs mean[F], obs var[F], obs count, ret mean, ret var, ret count */
     double* moments;                /* f64 [moments_len] all-reduce payload of the step in flight */
@@ -123,10 +131,17 @@ int gymhip_reset_finish(gymhip_engine* h, void* stream);
 int gymhip_rollout(gymhip_engine* h, const uint8_t* action_tape, int64_t k_steps, uint8_t* rec_done, float* rec_reward,
                    uint8_t* rec_truncated, float* rec_obs, void* stream);
 
+/* Expand the packed counter words into plain device lanes (any pointer may be NULL): elapsed_steps i32 [N]; and, valid
+ * where done != 0 (0 elsewhere), episode_length i32 [N] + episode_return f32 [N] = info["episode"].{l,r}
+ * (monitor.h:74-98) and truncated u8 [N] = info["TimeLimit.truncated"] (time_limit.h:32); tape_cursor i32 [N]. */
+int gymhip_decode_counters(gymhip_engine* h, int32_t* elapsed_steps, int32_t* episode_length, uint8_t* truncated,
+                           float* episode_return, int32_t* tape_cursor, void* stream);
+
 /* Reduce the per-block episode counters into episode_totals (device) and, if `host_out` is non-NULL, copy the three
  * doubles back (synchronises `stream`).  Monitor getters monitor.h:104-107 in aggregate form. */
 int gymhip_episode_stats(gymhip_engine* h, double* host_out, void* stream);
-/* Sticky device error word: bit0 = reset tape exhausted (an env needed more episodes than were uploaded). */
+/* Sticky device error word: bit0 = reset tape exhausted (an env needed more episodes than were uploaded; rows wrap),
+ * bit1 = an env's tape-cursor field overflowed (2^20 episodes). */
 int gymhip_poll_error(gymhip_engine* h, int32_t* host_out, void* stream);
 
 /* VecNormalize::save/load state (vec_normalize.h:79-108; running_mean_std.h:28-40) as 2F+4 floats, host side. */

@@ -18,6 +18,19 @@ def rel_err(a, b):
     return np.abs(a - b) / np.maximum(np.abs(b), 1e-2)   # abs floor 1e-2 as in SURVEY.md §7
 
 
+def check_episode_info(eng, r, d):
+    """info["episode"] / info["TimeLimit.truncated"] of the envs that just finished (decoded from the record words)."""
+    ln, tr, ret = (x.cpu().numpy() for x in eng.episode_info())
+    assert np.array_equal(tr[d], r["truncated"][d])
+    assert np.array_equal(ln[d].astype(np.float32), r["ep_l"][d])
+    assert np.array_equal(ret[d], r["ep_r"][d])
+    assert not ln[~d].any() and not tr[~d].any()
+    el = eng.counters()["elapsed"].cpu().numpy()
+    assert (el[~d] > 0).all() and (el[d] == 0).all()
+    w = eng.counter.cpu().numpy()
+    assert ((w < 0) == d).all()          # bit 31 of the packed word <=> the last step finished an episode
+
+
 def make_engine(kind, n, precision, wrappers, max_steps, reset_mode=None, seed=0, env_offset=0):
     from gym_amd import _lib as L
     from gym_amd.engine import Engine, EngineConfig
@@ -52,9 +65,7 @@ def test_cartpole_step_api_lockstep_every_step(oracle):
         d = r["done"] != 0
         if d.any():
             n_done += int(d.sum())
-            assert np.array_equal(eng.truncated.cpu().numpy()[d], r["truncated"][d])
-            assert np.array_equal(eng.last_episode_return.cpu().numpy()[d], r["ep_r"][d])
-            assert np.array_equal(eng.last_episode_length.cpu().numpy()[d].astype(np.float32), r["ep_l"][d])
+            check_episode_info(eng, r, d)
         if t % 250 == 0 or t == T - 1:
             # the fp64 state itself: bit-exact unless device sin/cos round differently from glibc (then <= 1e-12)
             st = eng.state64.cpu().numpy()                      # [2][n][2] double2 planes
@@ -120,9 +131,7 @@ def test_mountaincar_lockstep(oracle):
         assert rel_err(eng.obs.cpu().numpy(), r["obs"]).max() <= REL, t
         d = r["done"] != 0
         if d.any():
-            assert np.array_equal(eng.truncated.cpu().numpy()[d], r["truncated"][d])
-            assert np.array_equal(eng.last_episode_length.cpu().numpy()[d].astype(np.float32), r["ep_l"][d])
-            assert np.array_equal(eng.last_episode_return.cpu().numpy()[d], r["ep_r"][d])
+            check_episode_info(eng, r, d)
     assert eng.episode_stats()[0] == 3 * n   # every episode truncates at 200 under random actions
 
 
@@ -144,7 +153,7 @@ def test_mountaincar_goal_reached_directed_policy(oracle):
         assert np.array_equal(eng.done.cpu().numpy(), r["done"]), t
         d = r["done"] != 0
         if d.any():
-            assert np.array_equal(eng.truncated.cpu().numpy()[d], r["truncated"][d])
+            check_episode_info(eng, r, d)
             terminated += int((d & (r["truncated"] == 0)).sum())
         assert rel_err(eng.obs.cpu().numpy(), obs).max() <= REL
     assert terminated > 0
@@ -171,7 +180,7 @@ def test_cartpole_no_time_limit_uses_internal_500(oracle):
         d = r["done"] != 0
         if d.any():
             lens += list(r["ep_l"][d])
-            assert np.array_equal(eng.last_episode_length.cpu().numpy()[d].astype(np.float32), r["ep_l"][d])
+            check_episode_info(eng, r, d)
         assert rel_err(eng.obs.cpu().numpy(), obs).max() <= REL
     assert 501.0 in lens
 
