@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgymhip.so")
+LIB_PATH = os.environ.get("GYMHIP_LIB") or os.path.join(_HERE, "lib", "libgymhip.so")   # GYMHIP_LIB: tuning builds only
 
 OK = 0
 ENV_CARTPOLE, ENV_MOUNTAINCAR = 0, 1

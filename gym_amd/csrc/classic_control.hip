@@ -43,7 +43,8 @@ using namespace gymhip;
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kMaxGrid = 2048;  // 256 CUs x 8 resident blocks: grid-stride beyond that (guide §6 G11)
+constexpr int kMaxGrid = 8192;  // upper bound of the grid-stride launch (sizes the per-block partial buffers)
+constexpr int kDefaultGrid = 1024;  // 256 CUs x 4 blocks: best of the 512..8192 sweep (profiles/r01_sweep.txt); GYMHIP_GRID overrides
 constexpr int kMaxCols = 16;    // >= 2F+6 for F=4
 
 enum : int { KIND_CARTPOLE = GYMHIP_ENV_CARTPOLE, KIND_MOUNTAINCAR = GYMHIP_ENV_MOUNTAINCAR };
@@ -186,24 +187,47 @@ template <> struct EnvTraits<KIND_MOUNTAINCAR> { static constexpr int F = 2; sta
 // State I/O.  LOCKSTEP: double2 planes [F/2][N] (each plane a fully coalesced 16 B/lane stream) + f32 obs rows.
 // F32: the f32 obs rows [N][F] ARE the state (float4 / float2 per lane).
 // ------------------------------------------------------------------------------------------------------------
-template <int F> struct ObsVec;
-template <> struct ObsVec<4> { using type = float4; };
-template <> struct ObsVec<2> { using type = float2; };
+// Compile-time tuning knobs (profiles/ and DESIGN.md §5 record what each is worth on MI355X):
+//   GYMHIP_ILP  envs per thread per grid-stride iteration, all loads issued before the first dependent use
+//   GYMHIP_NT   1 = non-temporal loads/stores on the once-per-step streams (working set >> 256 MiB Infinity Cache)
+#ifndef GYMHIP_ILP
+#define GYMHIP_ILP 1
+#endif
+#ifndef GYMHIP_NT
+#define GYMHIP_NT 1
+#endif
+using f32x4 = float __attribute__((ext_vector_type(4)));
+using f32x2 = float __attribute__((ext_vector_type(2)));
+using f64x2 = double __attribute__((ext_vector_type(2)));
+template <typename V> __device__ inline V ld_stream(const V* ptr) {
+#if GYMHIP_NT
+    return __builtin_nontemporal_load(ptr);
+#else
+    return *ptr;
+#endif
+}
+template <typename V> __device__ inline void st_stream(V* ptr, V v) {
+#if GYMHIP_NT
+    __builtin_nontemporal_store(v, ptr);
+#else
+    *ptr = v;
+#endif
+}
 
 template <int F> __device__ inline void load_state(const StepBuffers& b, int64_t n, int64_t i, double (&s)[F]) {
-    const double2* pl = (const double2*)b.state;
+    const f64x2* pl = (const f64x2*)b.state;
 #pragma unroll
-    for (int k = 0; k < F / 2; k++) { double2 v = pl[(int64_t)k * n + i]; s[2 * k] = v.x; s[2 * k + 1] = v.y; }
+    for (int k = 0; k < F / 2; k++) { f64x2 v = ld_stream(pl + (int64_t)k * n + i); s[2 * k] = v.x; s[2 * k + 1] = v.y; }
 }
 template <int F> __device__ inline void store_state(const StepBuffers& b, int64_t n, int64_t i, const double (&s)[F]) {
-    double2* pl = (double2*)b.state;
+    f64x2* pl = (f64x2*)b.state;
 #pragma unroll
-    for (int k = 0; k < F / 2; k++) pl[(int64_t)k * n + i] = make_double2(s[2 * k], s[2 * k + 1]);
+    for (int k = 0; k < F / 2; k++) { f64x2 v = {s[2 * k], s[2 * k + 1]}; st_stream(pl + (int64_t)k * n + i, v); }
 }
-__device__ inline void load_obs(const float* obs, int64_t i, float (&s)[4]) { float4 v = ((const float4*)obs)[i]; s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w; }
-__device__ inline void load_obs(const float* obs, int64_t i, float (&s)[2]) { float2 v = ((const float2*)obs)[i]; s[0] = v.x; s[1] = v.y; }
-__device__ inline void store_obs(float* obs, int64_t i, const float (&s)[4]) { ((float4*)obs)[i] = make_float4(s[0], s[1], s[2], s[3]); }
-__device__ inline void store_obs(float* obs, int64_t i, const float (&s)[2]) { ((float2*)obs)[i] = make_float2(s[0], s[1]); }
+__device__ inline void load_obs(const float* obs, int64_t i, float (&s)[4]) { f32x4 v = ld_stream((const f32x4*)obs + i); s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w; }
+__device__ inline void load_obs(const float* obs, int64_t i, float (&s)[2]) { f32x2 v = ld_stream((const f32x2*)obs + i); s[0] = v.x; s[1] = v.y; }
+__device__ inline void store_obs(float* obs, int64_t i, const float (&s)[4]) { f32x4 v = {s[0], s[1], s[2], s[3]}; st_stream((f32x4*)obs + i, v); }
+__device__ inline void store_obs(float* obs, int64_t i, const float (&s)[2]) { f32x2 v = {s[0], s[1]}; st_stream((f32x2*)obs + i, v); }
 
 // Reset state of env i for episode `ep` (already range-checked).
 template <int KIND, typename T>
@@ -274,56 +298,77 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
     const bool tape_mode = KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE;
     const bool ret_lane = (p.wrappers & GYMHIP_WRAP_NORM_REWARD) && (p.wrappers & GYMHIP_WRAP_NORM_TRAINING);
 
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * kBlock) {
-        T s[F];
-        if constexpr (LOCKSTEP) load_state<F>(b, p.n, i, s); else load_obs(b.obs, i, s);
-        const int action = (int)actions[i];
-        const uint32_t w = b.counter[i];       // packed step counter / episode record / tape cursor (gymhip.h)
-        int t = CounterWord<KIND>::steps_now(w);
-        uint32_t cursor = CounterWord<KIND>::cursor(w);
-
-        bool env_done;
-        if constexpr (KIND == KIND_CARTPOLE) env_done = cartpole_step(s, action, t); else env_done = mountaincar_step(s, action);
-        t += 1;
-        bool done = env_done, trunc = false;
-        if (time_limit && t >= p.max_episode_steps) { trunc = !env_done; done = true; }   // time_limit.h:30-34
-        float reward = EnvTraits<KIND>::step_reward;
-        if (clip) reward = reward == 0.f ? reward : (reward > 0.f ? 1.f : -1.f);           // clip_reward.h:22-24
-
-        if (done) {
-            // Monitor (monitor.h:78-97): every step of these envs pays the same reward, so the ordered float sum of
-            // t copies equals float(t)*reward exactly (t < 2^24).  The finished episode's (length, truncated) and the
-            // reset-tape cursor live in the counter word, which is rewritten every step anyway: no extra HBM traffic
-            // and no scattered read-modify-write on the done path.
-            ep[0] += 1.0; ep[1] += (double)((float)t * reward); ep[2] += (double)t;
-            int64_t e;
-            if (tape_mode) {
-                e = cursor;
-                if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
-                cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
-            } else {
-                e = p.step_counter;            // stateless: (seed, env, global step) is unique per reset
+    constexpr int U = GYMHIP_ILP;
+    for (int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x; base < p.n; base += (int64_t)gridDim.x * (kBlock * U)) {
+        // phase 1: every load of the U envs this thread owns is issued before the first dependent instruction
+        T sv[U][F];
+        int action_v[U];
+        uint32_t w_v[U];
+        float ret_v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t i = base + (int64_t)u * kBlock;
+            if (i < p.n) {
+                if constexpr (LOCKSTEP) load_state<F>(b, p.n, i, sv[u]); else load_obs(b.obs, i, sv[u]);
+                action_v[u] = (int)ld_stream(actions + i);
+                w_v[u] = ld_stream(b.counter + i);   // packed step counter / episode record / tape cursor (gymhip.h)
+                if constexpr (NORM) ret_v[u] = ret_lane ? ld_stream(b.returns + i) : 0.f;
             }
-            reset_state<KIND, T>(p, i, e, s);   // sync_env.h:92-100: terminal obs replaced by the reset obs
         }
-
-        float o[F];
+        // phase 2: dynamics + fused wrappers + auto-reset + stores
 #pragma unroll
-        for (int f = 0; f < F; f++) o[f] = (float)s[f];
-        if constexpr (LOCKSTEP) store_state<F>(b, p.n, i, s);
-        store_obs(b.obs, i, o);
-        b.counter[i] = CounterWord<KIND>::pack(t, cursor, done, trunc);
-        b.reward[i] = reward;
-        b.done[i] = done ? 1.f : 0.f;
+        for (int u = 0; u < U; u++) {
+            const int64_t i = base + (int64_t)u * kBlock;
+            if (i >= p.n) continue;
+            T (&s)[F] = sv[u];
+            const int action = action_v[u];
+            const uint32_t w = w_v[u];
+            int t = CounterWord<KIND>::steps_now(w);
+            uint32_t cursor = CounterWord<KIND>::cursor(w);
 
-        if constexpr (NORM) {
+            bool env_done;
+            if constexpr (KIND == KIND_CARTPOLE) env_done = cartpole_step(s, action, t); else env_done = mountaincar_step(s, action);
+            t += 1;
+            bool done = env_done, trunc = false;
+            if (time_limit && t >= p.max_episode_steps) { trunc = !env_done; done = true; }   // time_limit.h:30-34
+            float reward = EnvTraits<KIND>::step_reward;
+            if (clip) reward = reward == 0.f ? reward : (reward > 0.f ? 1.f : -1.f);           // clip_reward.h:22-24
+
+            if (done) {
+                // Monitor (monitor.h:78-97): every step of these envs pays the same reward, so the ordered float sum
+                // of t copies equals float(t)*reward exactly (t < 2^24).  The finished episode's (length, truncated)
+                // and the reset-tape cursor live in the counter word, which is rewritten every step anyway: no extra
+                // HBM traffic and no scattered read-modify-write on the done path.
+                ep[0] += 1.0; ep[1] += (double)((float)t * reward); ep[2] += (double)t;
+                int64_t e;
+                if (tape_mode) {
+                    e = cursor;
+                    if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
+                    cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
+                } else {
+                    e = p.step_counter;            // stateless: (seed, env, global step) is unique per reset
+                }
+                reset_state<KIND, T>(p, i, e, s);   // sync_env.h:92-100: terminal obs replaced by the reset obs
+            }
+
+            float o[F];
 #pragma unroll
-            for (int f = 0; f < F; f++) { double d = (double)o[f] - (double)shift[f]; acc[f] += d; acc[F + f] += d * d; }
-            if (ret_lane) {
-                float r = b.returns[i] * p.gamma + reward;        // vec_normalize.h:132
-                double d = (double)r - (double)shift[F];
-                acc[2 * F] += d; acc[2 * F + 1] += d * d;
-                b.returns[i] = done ? 0.f : r;                    // vec_normalize.h:175 (applied after the RMS update)
+            for (int f = 0; f < F; f++) o[f] = (float)s[f];
+            if constexpr (LOCKSTEP) store_state<F>(b, p.n, i, s);
+            store_obs(b.obs, i, o);
+            st_stream(b.counter + i, CounterWord<KIND>::pack(t, cursor, done, trunc));
+            st_stream(b.reward + i, reward);
+            st_stream(b.done + i, done ? 1.f : 0.f);
+
+            if constexpr (NORM) {
+#pragma unroll
+                for (int f = 0; f < F; f++) { double d = (double)o[f] - (double)shift[f]; acc[f] += d; acc[F + f] += d * d; }
+                if (ret_lane) {
+                    float r = ret_v[u] * p.gamma + reward;            // vec_normalize.h:132
+                    double d = (double)r - (double)shift[F];
+                    acc[2 * F] += d; acc[2 * F + 1] += d * d;
+                    st_stream(b.returns + i, done ? 0.f : r);         // vec_normalize.h:175 (applied after the RMS update)
+                }
             }
         }
     }
@@ -592,8 +637,10 @@ bool valid_config(const gymhip_config* c) {
 }
 
 int grid_for(int64_t n) {
-    int64_t g = (n + kBlock - 1) / kBlock;
-    return (int)(g < kMaxGrid ? g : kMaxGrid);
+    int64_t cap = kDefaultGrid;
+    if (const char* e = getenv("GYMHIP_GRID")) { int v = atoi(e); if (v > 0 && v <= kMaxGrid) cap = v; }
+    int64_t g = (n + (int64_t)kBlock * GYMHIP_ILP - 1) / ((int64_t)kBlock * GYMHIP_ILP);
+    return (int)(g < cap ? g : cap);
 }
 
 Layout make_layout(const gymhip_config& c) {
