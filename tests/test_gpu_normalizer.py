@@ -1,0 +1,174 @@
+"""GPU parity of the fused VecNormalize path (BASELINE config 3) against the CPU oracle.
+
+What is compared, per step (SURVEY.md §7 "Normaliser ordering"):
+  (i)   raw obs / reward / done streams: exact (same bar as the lockstep tests);
+  (ii)  running (mean, var, count) of the obs and return statistics: <= 1e-5 relative;
+  (iii) normalised obs / reward: <= 1e-5 scaled by the conditioning of (x - mean)/sqrt(var + eps), i.e. absolute
+        tolerance 1e-5 * max(1, |mean| / sqrt(var + eps)) — while every MountainCar env still sits at the identical
+        start state the batch variance is ~0 and the division amplifies the last-bit difference between two float32
+        batch-mean reduction orders by up to 1e4 (measured in the survey against the compiled reference).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.oracle_lib import CARTPOLE, MOUNTAINCAR, F_CLIP_REWARD, F_MONITOR, F_TIME_LIMIT, splitmix_actions
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(kind, n, wrappers, max_steps, env_offset=0, precision=None):
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+    return Engine(EngineConfig(env_kind=kind, n_envs=n, precision=L.PRECISION_LOCKSTEP_F64 if precision is None else precision,
+                               reset_mode=L.RESET_TAPE, wrappers=wrappers, max_episode_steps=max_steps, env_offset=env_offset), 0)
+
+
+def _norm_flags():
+    from gym_amd import _lib as L
+    return L.WRAP_NORM_OBS | L.WRAP_NORM_REWARD | L.WRAP_NORM_TRAINING
+
+
+def _check_stats(g, o, F, where):
+    # g, o: [mean F, var F, count, ret mean, ret var, ret count]
+    err = np.abs(g - o) / np.maximum(np.abs(o), 1e-6)
+    assert err.max() <= 1e-5, f"running stats diverged at {where}: {err}\n{g}\n{o}"
+
+
+def _check_normalised(g_obs, o_obs, g_rew, o_rew, stats, F, eps, where):
+    mean, var = stats[:F], stats[F:2 * F]
+    cond = np.maximum(1.0, np.abs(mean) / np.sqrt(var + eps))
+    assert (np.abs(g_obs - o_obs) <= 1e-5 * cond * np.maximum(1.0, np.abs(o_obs))).all(), f"normalised obs diverged at {where}"
+    assert (np.abs(g_rew - o_rew) <= 1e-5 * np.maximum(1.0, np.abs(o_rew))).all(), f"normalised reward diverged at {where}"
+
+
+@pytest.mark.parametrize("n,T", [(4096, 450), (1 << 20, 60)])
+def test_mountaincar_vecnormalize_config3(oracle, n, T):
+    """MountainCar + TimeLimit(200) + ClipReward + Monitor + TrainingVecNormRO (config 3; N = 1,048,576 is its full size)."""
+    from gym_amd import _lib as L
+    ov = oracle.vec(MOUNTAINCAR, n, F_TIME_LIMIT | F_CLIP_REWARD | F_MONITOR, 200)
+    ov.attach_norm()
+    eng = _engine(L.ENV_MOUNTAINCAR, n, L.WRAP_TIME_LIMIT | L.WRAP_CLIP_REWARD | L.WRAP_MONITOR | _norm_flags(), 200)
+    eng.reset()
+    o_obs, o_raw = ov.norm_reset()
+    assert np.array_equal(eng.obs.cpu().numpy(), o_raw)
+    _check_stats(eng.get_norm_stats(), ov.norm_stats(), 2, "reset")
+    _check_normalised(eng.obs_norm.cpu().numpy(), o_obs, np.zeros(n, np.float32), np.zeros(n, np.float32), ov.norm_stats(), 2, 1e-8, "reset")
+    acts = splitmix_actions(5, T, n, 3)
+    dev = torch.from_numpy(acts).cuda()
+    for t in range(T):
+        eng.step(dev[t])
+        r = ov.norm_step(acts[t])
+        assert np.array_equal(eng.obs.cpu().numpy(), r["raw_obs"]), t
+        assert np.array_equal(eng.done.cpu().numpy(), r["done"]), t
+        st = ov.norm_stats()
+        _check_stats(eng.get_norm_stats(), st, 2, f"step {t}")
+        _check_normalised(eng.obs_norm.cpu().numpy(), r["obs"], eng.reward.cpu().numpy(), r["reward"], st, 2, 1e-8, f"step {t}")
+        ret_err = np.abs(eng.returns.cpu().numpy() - ov.norm_returns())
+        assert ret_err.max() <= 1e-5 * max(1.0, np.abs(ov.norm_returns()).max())
+    assert np.array_equal(eng.norm_stats.cpu().numpy(), eng.get_norm_stats())   # public copy == current slot
+
+
+def test_cartpole_vecnormalize(oracle):
+    """CartPole + Monitor + TrainingVecNormRO (the stack of test/classic_control.cpp:105-107), N=8192 x 400 steps."""
+    from gym_amd import _lib as L
+    n, T = 8192, 400
+    ov = oracle.vec(CARTPOLE, n, F_MONITOR, 0)
+    ov.seed(11)
+    ov.attach_norm()
+    eng = _engine(L.ENV_CARTPOLE, n, L.WRAP_MONITOR | _norm_flags(), 0)
+    eng.upload_reset_tape(oracle.cartpole_reset_tape(11, n, T // 8 + 4))
+    eng.reset()
+    o_obs, o_raw = ov.norm_reset()
+    assert np.array_equal(eng.obs.cpu().numpy(), o_raw)
+    _check_stats(eng.get_norm_stats(), ov.norm_stats(), 4, "reset")
+    acts = splitmix_actions(6, T, n, 2)
+    dev = torch.from_numpy(acts).cuda()
+    for t in range(T):
+        eng.step(dev[t])
+        r = ov.norm_step(acts[t])
+        assert np.array_equal(eng.obs.cpu().numpy(), r["raw_obs"]), t
+        assert np.array_equal(eng.done.cpu().numpy(), r["done"]), t
+        st = ov.norm_stats()
+        _check_stats(eng.get_norm_stats(), st, 4, f"step {t}")
+        _check_normalised(eng.obs_norm.cpu().numpy(), r["obs"], eng.reward.cpu().numpy(), r["reward"], st, 4, 1e-8, f"step {t}")
+    assert eng.poll_error() == 0
+
+
+def test_first_normalised_rewards_match_reference_probe(oracle):
+    """SURVEY.md §8a A10 [probed on the compiled reference]: first CartPole step => normalised reward 10 (clipped),
+    second => 2.02."""
+    from gym_amd import _lib as L
+    n = 4
+    eng = _engine(L.ENV_CARTPOLE, n, L.WRAP_MONITOR | _norm_flags(), 0)
+    eng.upload_reset_tape(oracle.cartpole_reset_tape(0, n, 8))
+    eng.reset()
+    a = torch.ones(n, dtype=torch.int32, device="cuda")
+    eng.step(a)
+    assert np.array_equal(eng.reward.cpu().numpy(), np.full(n, 10.0, np.float32))
+    eng.step(a)
+    assert np.allclose(eng.reward.cpu().numpy(), 2.02, atol=5e-3)
+
+
+def test_sharded_moments_allreduce_equals_single_engine(oracle):
+    """Two engines holding the two halves of the env range, with the `moments` payloads summed between
+    step_begin and step_finish (what the RCCL all-reduce does across ranks), must track the single-engine run:
+    raw streams exactly, running statistics to 1e-6, normalised outputs to 1e-5 (conditioning-scaled)."""
+    from gym_amd import _lib as L
+    n, T = 16384, 260
+    w = L.WRAP_TIME_LIMIT | L.WRAP_CLIP_REWARD | L.WRAP_MONITOR | _norm_flags()
+    one = _engine(L.ENV_MOUNTAINCAR, n, w, 200)
+    halves = [_engine(L.ENV_MOUNTAINCAR, n // 2, w, 200, env_offset=k * n // 2) for k in range(2)]
+
+    def allreduce():
+        tot = halves[0].moments + halves[1].moments
+        for h in halves:
+            h.moments.copy_(tot)
+
+    one.reset()
+    for h in halves:
+        h.reset_begin()
+    allreduce()
+    for h in halves:
+        h.reset_finish()
+    acts = torch.from_numpy(splitmix_actions(8, T, n, 3)).cuda()
+    for t in range(T):
+        one.step(acts[t])
+        for k, h in enumerate(halves):
+            h.step_begin(acts[t, k * n // 2:(k + 1) * n // 2])
+        allreduce()
+        assert float(halves[0].moments[0]) == n          # global batch count
+        for h in halves:
+            h.step_finish()
+        s1 = one.get_norm_stats()
+        for k, h in enumerate(halves):
+            sl = slice(k * n // 2, (k + 1) * n // 2)
+            assert torch.equal(h.obs, one.obs[sl]) and torch.equal(h.done, one.done[sl])
+            s2 = h.get_norm_stats()
+            assert (np.abs(s1 - s2) <= 1e-6 * np.maximum(np.abs(s1), 1e-6)).all(), (t, s1, s2)
+            cond = np.maximum(1.0, np.abs(s1[:2]) / np.sqrt(s1[2:4] + 1e-8))
+            d = (h.obs_norm - one.obs_norm[sl]).abs().cpu().numpy()
+            assert (d <= 1e-5 * cond * np.maximum(1.0, one.obs_norm[sl].abs().cpu().numpy())).all(), t
+            assert torch.allclose(h.reward, one.reward[sl], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(halves[0].get_norm_stats(), halves[1].get_norm_stats())   # replicated statistics stay identical
+
+
+def test_norm_stats_save_load_roundtrip():
+    from gym_amd import _lib as L
+    n = 1024
+    w = L.WRAP_TIME_LIMIT | L.WRAP_MONITOR | _norm_flags()
+    a = _engine(L.ENV_MOUNTAINCAR, n, w, 200)
+    a.reset()
+    acts = torch.randint(0, 3, (50, n), dtype=torch.int32, device="cuda")
+    for t in range(25):
+        a.step(acts[t])
+    saved = a.get_norm_stats()
+    b = _engine(L.ENV_MOUNTAINCAR, n, w & ~L.WRAP_NORM_TRAINING, 200)   # evaluation copy: isTraining=false
+    b.set_norm_stats(saved)
+    b.reset()
+    for t in range(25):
+        b.step(acts[t])
+    assert np.array_equal(b.get_norm_stats(), saved)                    # frozen statistics
+    mean, var = saved[:2], saved[2:4]
+    want = np.clip((b.obs.cpu().numpy() - mean) / np.sqrt(var + np.float32(1e-8)), -10, 10)
+    assert np.allclose(b.obs_norm.cpu().numpy(), want, rtol=1e-6, atol=1e-6)
