@@ -68,6 +68,7 @@ class AtariConfig(C.Structure):
         ("dst_w", C.c_int32),
         ("n_stack", C.c_int32),
         ("gray_bits", C.c_int32),
+        ("clear_on_done", C.c_int32),
     ]
 
 
@@ -96,9 +97,7 @@ SIGNATURES = {
     "gymhip_poll_error": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_get_norm_stats": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_set_norm_stats": (C.c_int, [_vp, _vp, _vp]),
-}
-PENDING_SIGNATURES = {
-    "gymhip_host_env_post_step": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gymhip_host_env_post_step": (C.c_int, [_i64] + [_vp] * 7 + [C.c_int] + [_vp] * 6),
     "gymhip_atari_create": (C.c_int, [C.POINTER(AtariConfig), C.c_int, C.POINTER(_vp)]),
     "gymhip_atari_destroy": (C.c_int, [_vp]),
     "gymhip_atari_stack_buffer": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_i32)]),

@@ -1,0 +1,103 @@
+"""Python owner of a gymhip_atari handle: MaxAndSkip max + WarpFrame + VecFrameStack [+ VecNormAndPermute] on device.
+
+Mirrors the reference's Atari wrapper chain for the part that is not emulation; ALE itself stays on
+the host and hands over frames u8 [N][2][210][160][3] in device memory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class AtariPreprocessor:
+    def __init__(self, n_envs: int, n_stack: int = 4, src_hw=(210, 160), dst_hw=(84, 84), gray_bits: int = 15,
+                 clear_on_done: bool = False, device: int = 0):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.GymhipError("no GPU visible: the gymhip engine has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        c = L.AtariConfig()
+        c.struct_size = C.sizeof(L.AtariConfig)
+        c.n_envs, c.src_h, c.src_w, c.dst_h, c.dst_w = n_envs, src_hw[0], src_hw[1], dst_hw[0], dst_hw[1]
+        c.n_stack, c.gray_bits, c.clear_on_done = n_stack, gray_bits, int(clear_on_done)
+        self.cfg = c
+        h = C.c_void_p()
+        L.check(self.lib.gymhip_atari_create(C.byref(c), device, C.byref(h)), "gymhip_atari_create")
+        self.h = h
+        self.n, self.k, self.dst_hw, self.src_hw = n_envs, n_stack, dst_hw, src_hw
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gymhip_atari_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _frames(self, frames: torch.Tensor):
+        want = (self.n, 2, self.src_hw[0], self.src_hw[1], 3)
+        if frames.dtype != torch.uint8 or tuple(frames.shape) != want or not frames.is_contiguous() or frames.device != self.device:
+            raise ValueError(f"frames must be a contiguous uint8 {want} tensor on {self.device}")
+        return C.c_void_p(frames.data_ptr())
+
+    def preprocess(self, frames: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty((self.n, *self.dst_hw), dtype=torch.uint8, device=self.device)
+        L.check(self.lib.gymhip_atari_preprocess(self.h, self._frames(frames), C.c_void_p(out.data_ptr()), self._stream()), "gymhip_atari_preprocess")
+        return out
+
+    def reset(self, frames: torch.Tensor):
+        L.check(self.lib.gymhip_atari_reset(self.h, self._frames(frames), self._stream()), "gymhip_atari_reset")
+
+    def step(self, frames: torch.Tensor, done: torch.Tensor | None = None):
+        dp = None
+        if done is not None:
+            if done.dtype != torch.uint8 or done.numel() != self.n or not done.is_contiguous():
+                raise ValueError("done must be a contiguous uint8 [n_envs] tensor")
+            dp = C.c_void_p(done.data_ptr())
+        L.check(self.lib.gymhip_atari_step(self.h, self._frames(frames), dp, self._stream()), "gymhip_atari_step")
+
+    def head(self) -> int:
+        ring, head = C.c_void_p(), C.c_int32()
+        L.check(self.lib.gymhip_atari_stack_buffer(self.h, C.byref(ring), C.byref(head)), "gymhip_atari_stack_buffer")
+        return head.value
+
+    def stacked_nhwc(self, out: torch.Tensor | None = None) -> torch.Tensor:
+        """VecFrameStack observation: uint8 [N, 84, 84, k], oldest frame in channel 0."""
+        if out is None:
+            out = torch.empty((self.n, *self.dst_hw, self.k), dtype=torch.uint8, device=self.device)
+        L.check(self.lib.gymhip_atari_materialize_nhwc(self.h, C.c_void_p(out.data_ptr()), self._stream()), "gymhip_atari_materialize_nhwc")
+        return out
+
+    def stacked_nchw_f32(self, out: torch.Tensor | None = None) -> torch.Tensor:
+        """VecNormAndPermute(VecFrameStack(...)) observation: float32 [N, k, 84, 84] in [0, 1]."""
+        if out is None:
+            out = torch.empty((self.n, self.k, *self.dst_hw), dtype=torch.float32, device=self.device)
+        L.check(self.lib.gymhip_atari_materialize_nchw_f32(self.h, C.c_void_p(out.data_ptr()), self._stream()), "gymhip_atari_materialize_nchw_f32")
+        return out
+
+
+def host_env_post_step(reward, done, lives, state: dict, clip_reward: bool = True):
+    """Fused Monitor -> EpisodicLife -> ClipReward lanes for host-emulated envs (gymhip_host_env_post_step).
+    `state`: dict(lives i32, was_real_done u8, ret f32, len f32) device tensors, updated in place."""
+    lib = L.load()
+    n = reward.numel()
+    dev = reward.device
+    out = dict(reward=torch.empty(n, dtype=torch.float32, device=dev), done=torch.empty(n, dtype=torch.uint8, device=dev),
+               has_ep=torch.empty(n, dtype=torch.uint8, device=dev), ep_r=torch.empty(n, dtype=torch.float32, device=dev),
+               ep_l=torch.empty(n, dtype=torch.float32, device=dev))
+    p = lambda t: C.c_void_p(t.data_ptr())
+    L.check(lib.gymhip_host_env_post_step(n, p(reward), p(done), p(lives), p(state["lives"]), p(state["was_real_done"]), p(state["ret"]),
+                                          p(state["len"]), int(clip_reward), p(out["reward"]), p(out["done"]), p(out["has_ep"]),
+                                          p(out["ep_r"]), p(out["ep_l"]), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+            "gymhip_host_env_post_step")
+    return out

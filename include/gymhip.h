@@ -148,6 +148,57 @@ int gymhip_poll_error(gymhip_engine* h, int32_t* host_out, void* stream);
 int gymhip_get_norm_stats(gymhip_engine* h, float* host_out, void* stream);
 int gymhip_set_norm_stats(gymhip_engine* h, const float* host_in, void* stream);
 
+/* ======================================================================================================================
+ * Atari preprocessing (emulation stays on the host; frames arrive in device memory)
+ * ==================================================================================================================== */
+typedef struct gymhip_atari gymhip_atari;
+
+typedef struct gymhip_atari_config {
+    int32_t struct_size;    /* = sizeof(gymhip_atari_config) */
+    int64_t n_envs;
+    int32_t src_h, src_w;   /* 210, 160: AtariEnv's cv::Mat(210,160,CV_8UC3) RGB frame (atari/atari_env.cpp:101-113) */
+    int32_t dst_h, dst_w;   /* 84, 84: WarpFrameEnv(width, height) (warp_frame.h:21-30) */
+    int32_t n_stack;        /* VecFrameStack nStack (vec_frame_stack.cpp:10-16) */
+    int32_t gray_bits;      /* 15 (OpenCV 4.x RGB2GRAY fixed point) or 14 (older builds); they differ by <= 1 LSB */
+    int32_t clear_on_done;  /* 0 = as the reference (the stack is never cleared on done); 1 = SB3 semantics */
+} gymhip_atari_config;
+
+/* Replaces constructing MaxAndSkipEnv + WarpFrameEnv per env and VecFrameStack over them (atari_wrappers.cpp:95-121,
+ * vec_frame_stack.cpp:10-20).  Owns the frame-stack ring u8 [n_envs][n_stack][dst_h*dst_w] (zero-initialised). */
+int gymhip_atari_create(const gymhip_atari_config* cfg, int device, gymhip_atari** out);
+int gymhip_atari_destroy(gymhip_atari* h);
+/* Zero-copy access to the ring: plane (e, s) holds frame  t - ((head - s) mod n_stack)  of env e; `head` is the newest. */
+int gymhip_atari_stack_buffer(gymhip_atari* h, uint8_t** ring, int32_t* head);
+
+/* `frames`: device u8 [n_envs][2][src_h][src_w][3] — MaxAndSkipEnv's two observation buffers (frames skip-2 and skip-1
+ * of the group; the host front-end overwrites only the slot it has a new frame for, which reproduces "buffers keep
+ * older frames when the loop breaks on done", atari_wrappers.cpp:16-28).  Each call computes
+ * resize_area(gray(max(buf0, buf1))) per env: atari_wrappers.cpp:30 + warp_frame.h:41-47.
+ *   _preprocess: stateless, writes u8 [n_envs][dst_h][dst_w] to `out`.
+ *   _reset: VecFrameStack::reset (vec_frame_stack.cpp:22-25; stacked_observation.h:106-109): zero the stack, newest last.
+ *   _step:  VecFrameStack::stepWait (vec_frame_stack.cpp:27-32): shift by one frame, write the newest (INTENDED
+ *           semantics of stacked_observation.h:126-130 — the reference as written mis-indexes the write).
+ *           `done` (device u8 [n_envs], may be NULL) only matters with clear_on_done. */
+int gymhip_atari_preprocess(gymhip_atari* h, const uint8_t* frames, uint8_t* out, void* stream);
+int gymhip_atari_reset(gymhip_atari* h, const uint8_t* frames, void* stream);
+int gymhip_atari_step(gymhip_atari* h, const uint8_t* frames, const uint8_t* done, void* stream);
+/* The stacked observation as a contiguous tensor: channels-last u8 [n_envs][dst_h][dst_w][n_stack], oldest frame in
+ * channel 0 (what VecFrameStack returns over WarpFrame's {84,84,1} space, stacked_observation.h:96-99,203-209). */
+int gymhip_atari_materialize_nhwc(gymhip_atari* h, uint8_t* out, void* stream);
+/* VecNormAndPermute::observation fused onto the ring (vec_atari.cpp:70-81): f32 [n_envs][n_stack][dst_h][dst_w] = x / 255. */
+int gymhip_atari_materialize_nchw_f32(gymhip_atari* h, float* out, void* stream);
+
+/* Monitor -> EpisodicLifeEnv -> ClipRewardEnv for host-emulated envs, in AtariWrapper::make's order
+ * (atari_wrappers.cpp:95-121), over device lanes of n envs.  Inputs per env: the MaxAndSkip-summed reward, the
+ * emulator's done, info["ale.lives"].  Per-env state (updated in place): m_Lives, m_WasRealDone
+ * (episodic_life.h:16-17), Monitor's running return and length (monitor.h:116-117).  Outputs: clipped reward
+ * (clip_reward.h:22-24), done after the life-loss rule (atari_wrappers.cpp:35-47), info["episode"] lanes
+ * (monitor.h:80-98; has_episode marks REAL game-overs, where the host must do a real reset; on a life-loss done it
+ * steps the emulator with action 0 instead, atari_wrappers.cpp:49-53). */
+int gymhip_host_env_post_step(int64_t n, const float* reward_in, const uint8_t* done_in, const int32_t* lives_in, int32_t* st_lives,
+                              uint8_t* st_was_real_done, float* st_return, float* st_length, int clip_reward, float* reward_out,
+                              uint8_t* done_out, uint8_t* has_episode, float* ep_return, float* ep_length, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

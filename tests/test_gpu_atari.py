@@ -1,0 +1,174 @@
+"""GPU parity of the Atari preprocessing kernels (BASELINE config 4) against the
+CPU oracle.  Contract: resized uint8 frames within +-1 LSB (they are in fact compared exactly, since both sides follow
+the same op order), frame stack / permute / wrapper lanes exact.
+
+The oracle's resize/gray restate OpenCV 4.x, which is NOT in this image: parity with OpenCV itself is unpinned
+(oracle/gym_oracle.cpp header); hand-derived known answers live in tests/test_oracle_atari.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+H, W = 210, 160
+
+
+def counter_frames(seed, n, t=0):
+    """Synthetic frames u8 [n][2][210][160][3] from a counter hash of (seed, env, t, pixel)."""
+    idx = np.arange(n * 2 * H * W * 3, dtype=np.uint64) + np.uint64(seed * 0x9E3779B1 + t * 0x85EBCA77)
+    with np.errstate(over="ignore"):
+        z = idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(29))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = z ^ (z >> np.uint64(32))
+    return (z & np.uint64(255)).astype(np.uint8).reshape(n, 2, H, W, 3)
+
+
+def structured_frames():
+    """Edge cases: constants, gradients, single-pixel impulses, one frame dominating the max."""
+    fr = np.zeros((8, 2, H, W, 3), np.uint8)
+    fr[1] = 255
+    fr[2, 0] = 17; fr[2, 1] = 200                                   # max picks frame 1 everywhere
+    fr[3, 0, :, :, 0] = np.arange(W, dtype=np.uint8)[None, :]       # horizontal ramp in R
+    fr[3, 1, :, :, 1] = (np.arange(H) % 256).astype(np.uint8)[:, None]  # vertical ramp in G
+    fr[4, 0, 100, 77] = (255, 255, 255)                             # impulse
+    fr[4, 1, 0, 0] = (255, 0, 0); fr[4, 1, H - 1, W - 1] = (0, 0, 255)  # corners
+    rng = np.random.default_rng(3)
+    fr[5] = rng.integers(0, 256, fr[5].shape, dtype=np.uint8)
+    fr[6, 0] = fr[5, 1]; fr[6, 1] = fr[5, 0]                        # max is symmetric
+    fr[7, :, ::2] = 255                                             # stripes: exercises the 5:2 vertical taps
+    return fr
+
+
+@pytest.mark.parametrize("gray_bits", [15, 14])
+def test_preprocess_structured_and_random(oracle, gray_bits):
+    from gym_amd.atari import AtariPreprocessor
+    fr = np.concatenate([structured_frames(), counter_frames(7, 24)], axis=0)
+    n = fr.shape[0]
+    pp = AtariPreprocessor(n, gray_bits=gray_bits)
+    got = pp.preprocess(torch.from_numpy(fr).cuda()).cpu().numpy()
+    want = oracle.atari_preprocess(fr, gray15=int(gray_bits == 15))
+    diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert diff.max() <= 1, f"max LSB error {diff.max()}"
+    assert (diff != 0).mean() == 0.0, "same op order on both sides: expected bit-exact"
+    assert np.array_equal(got[5], got[6])                           # max(a,b) == max(b,a)
+    assert (got[0] == 0).all() and (got[1] == 255).all() and (got[2] == 200).all()
+
+
+def test_frame_stack_ring_matches_shift_semantics(oracle):
+    """reset + 9 steps (> 2 ring revolutions for k=4): NHWC stack and the NCHW/255 float view vs the oracle."""
+    from gym_amd.atari import AtariPreprocessor
+    n, k = 16, 4
+    pp = AtariPreprocessor(n, n_stack=k)
+    stack = np.zeros((n, 84, 84, k), np.uint8)
+    f0 = counter_frames(1, n, 0)
+    pp.reset(torch.from_numpy(f0).cuda())
+    oracle.framestack_reset(stack, oracle.atari_preprocess(f0))
+    assert np.array_equal(pp.stacked_nhwc().cpu().numpy(), stack)
+    assert (stack[..., :k - 1] == 0).all()
+    for t in range(1, 10):
+        f = counter_frames(1, n, t)
+        pp.step(torch.from_numpy(f).cuda())
+        oracle.framestack_update(stack, oracle.atari_preprocess(f))
+        assert np.array_equal(pp.stacked_nhwc().cpu().numpy(), stack), t
+        assert np.array_equal(pp.stacked_nchw_f32().cpu().numpy(), oracle.norm_permute(stack)), t
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_frame_stack_other_depths(oracle, k):
+    from gym_amd.atari import AtariPreprocessor
+    n = 4
+    pp = AtariPreprocessor(n, n_stack=k)
+    stack = np.zeros((n, 84, 84, k), np.uint8)
+    f0 = counter_frames(2, n, 0)
+    pp.reset(torch.from_numpy(f0).cuda())
+    oracle.framestack_reset(stack, oracle.atari_preprocess(f0))
+    for t in range(1, 5):
+        f = counter_frames(2, n, t)
+        pp.step(torch.from_numpy(f).cuda())
+        oracle.framestack_update(stack, oracle.atari_preprocess(f))
+        assert np.array_equal(pp.stacked_nhwc().cpu().numpy(), stack)
+        assert np.array_equal(pp.stacked_nchw_f32().cpu().numpy(), oracle.norm_permute(stack))
+
+
+def test_clear_on_done_option():
+    """clear_on_done=1 (SB3 semantics; the reference never clears): finished envs see zeros in the older channels."""
+    from gym_amd.atari import AtariPreprocessor
+    n = 6
+    pp = AtariPreprocessor(n, clear_on_done=True)
+    ref = AtariPreprocessor(n, clear_on_done=False)
+    for t in range(3):
+        f = torch.from_numpy(counter_frames(4, n, t)).cuda()
+        (pp.reset if t == 0 else pp.step)(f)
+        (ref.reset if t == 0 else ref.step)(f)
+    done = torch.tensor([0, 1, 0, 0, 1, 0], dtype=torch.uint8, device="cuda")
+    f = torch.from_numpy(counter_frames(4, n, 3)).cuda()
+    pp.step(f, done)
+    ref.step(f, done)
+    a, b = pp.stacked_nhwc().cpu().numpy(), ref.stacked_nhwc().cpu().numpy()
+    d = done.cpu().numpy().astype(bool)
+    assert np.array_equal(a[~d], b[~d])
+    assert np.array_equal(a[d][..., -1], b[d][..., -1]) and (a[d][..., :-1] == 0).all() and (b[d][..., :-1] != 0).any()
+
+
+def test_config4_full_size_properties():
+    """BASELINE config 4 at full size (4096 envs, 826 MB of frames): size-independent properties —
+    (1) every env given the same frame pair yields the same 84x84 image (and equals the small-batch result);
+    (2) max idempotence: (f, f) == preprocess of f alone; (3) monotonicity: raising pixel values never lowers outputs."""
+    from gym_amd.atari import AtariPreprocessor
+    n = 4096
+    base = torch.from_numpy(counter_frames(9, 2)).cuda()              # [2][2][H][W][3]
+    frames = base[:1].expand(n, 2, H, W, 3).contiguous()
+    frames[1::2] = base[1]
+    pp = AtariPreprocessor(n)
+    out = pp.preprocess(frames)
+    small = AtariPreprocessor(2).preprocess(base)
+    assert torch.equal(out[0::2], small[0].expand(n // 2, 84, 84)) and torch.equal(out[1::2], small[1].expand(n // 2, 84, 84))
+    same = frames.clone(); same[:, 1] = same[:, 0]
+    lone = pp.preprocess(same)
+    brighter = torch.maximum(same, torch.full_like(same, 128))
+    assert (pp.preprocess(brighter) >= lone).all()
+    pp.reset(frames)
+    pp.step(same)
+    st = pp.stacked_nhwc()
+    assert torch.equal(st[..., -1], lone) and torch.equal(st[..., -2], out) and (st[..., :2] == 0).all()
+
+
+def test_host_env_post_step_lanes(oracle):
+    """EpisodicLife + Monitor + ClipReward lanes over scripted (reward, done, lives) streams."""
+    from gym_amd.atari import host_env_post_step
+    n, T = 4096, 300
+    rng = np.random.default_rng(0)
+    lives = np.full(n, 5, np.int32)
+    st_o = dict(lives=np.zeros(n, np.int32), was_real_done=np.ones(n, np.uint8), ret=np.zeros(n, np.float32), len=np.zeros(n, np.float32))
+    st_g = {k: torch.from_numpy(v.copy()).cuda() for k, v in st_o.items()}
+    saw_life_done = saw_real_done = 0
+    for t in range(T):
+        rew = rng.choice(np.array([0.0, 0.0, 1.0, -3.0, 7.5, 0.25], np.float32), n).astype(np.float32)
+        lose = rng.random(n) < 0.03
+        lives = np.where(lose, lives - 1, lives).astype(np.int32)
+        done = (lives <= 0).astype(np.uint8)
+        want = oracle.host_env_post_step(rew, done, lives, st_o, clip=1)
+        got = host_env_post_step(torch.from_numpy(rew).cuda(), torch.from_numpy(done).cuda(), torch.from_numpy(lives).cuda(), st_g, True)
+        for key in ("reward", "done", "has_ep", "ep_r", "ep_l"):
+            assert np.array_equal(got[key].cpu().numpy(), want[key]), (t, key)
+        for key in st_o:
+            assert np.array_equal(st_g[key].cpu().numpy(), st_o[key]), (t, key)
+        saw_life_done += int(((want["done"] != 0) & (done == 0)).sum())
+        saw_real_done += int(done.sum())
+        lives = np.where(done != 0, 5, lives).astype(np.int32)       # real reset restores the lives
+    assert saw_life_done > 0 and saw_real_done > 0
+
+
+def test_atari_errors():
+    from gym_amd import _lib as L
+    from gym_amd.atari import AtariPreprocessor
+    with pytest.raises(L.GymhipError):
+        AtariPreprocessor(4, dst_hw=(84, 83))
+    with pytest.raises(L.GymhipError):
+        AtariPreprocessor(4, gray_bits=12)
+    pp = AtariPreprocessor(4)
+    with pytest.raises(L.GymhipError, match="before reset"):
+        pp.step(torch.zeros((4, 2, H, W, 3), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError):
+        pp.preprocess(torch.zeros((4, 2, H, W, 4), dtype=torch.uint8, device="cuda"))
