@@ -144,6 +144,84 @@ def main():
             "achieved_gbs": achieved, "bytes_per_env_step": bps, "error_flag": err, "episodes": eps[0],
         }
 
+    def measure_config3(n3, steps):
+        """BASELINE configs[2]: MountainCar + TimeLimit(200) + ClipReward + Monitor + obs/return normaliser; with more than one
+        rank the per-step batch moments + episode statistics (12 doubles) are all-reduced over RCCL between the step and the
+        normalise kernels.  n3 envs PER GPU."""
+        w = (L.WRAP_TIME_LIMIT | L.WRAP_CLIP_REWARD | L.WRAP_MONITOR | L.WRAP_NORM_OBS | L.WRAP_NORM_REWARD | L.WRAP_NORM_TRAINING)
+        eng = Engine(EngineConfig(env_kind=L.ENV_MOUNTAINCAR, n_envs=n3, precision=L.PRECISION_LOCKSTEP_F64, reset_mode=L.RESET_COUNTER_RNG,
+                                  wrappers=w, max_episode_steps=200, env_offset=rank * n3), local_rank)
+
+        def do_reset():
+            eng.reset_begin()
+            if world > 1:
+                dist.all_reduce(eng.moments)
+            eng.reset_finish()
+
+        def do_step(a):
+            eng.step_begin(a)
+            if world > 1:
+                dist.all_reduce(eng.moments)
+            eng.step_finish()
+
+        do_reset()
+        g = torch.Generator(device="cuda").manual_seed(77 + rank)
+        acts = [torch.randint(0, 3, (n3,), dtype=torch.int32, device="cuda", generator=g) for _ in range(4)]
+        for k in range(10):
+            do_step(acts[k % 4])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            do_step(acts[k % 4])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        stats = eng.get_norm_stats()
+        eng.close()
+        bps = 16 + 16 + 8 + 4 + 8 + 8 + 4 + 4 + (8 + 8 + 4 + 4)   # step kernel 68 B + normalise kernel 24 B (DESIGN.md §4)
+        return {"value": world * n3 * steps / dt, "unit": "env-steps/s", "envs_per_gpu": n3, "ms_per_step": round(dt / steps * 1e3, 4),
+                "bytes_per_env_step": bps, "achieved_GBs": round(bps * n3 * steps / dt / 1e9, 1), "collective": "all_reduce(12 x f64)/step" if world > 1 else None,
+                "obs_count": float(stats[4])}
+
+    def measure_atari(n4, steps):
+        """BASELINE configs[3]: 4096 envs, MaxAndSkip max + WarpFrame 84x84 gray + FrameStack(4) ring write, synthetic frames."""
+        from gym_amd.atari import AtariPreprocessor
+        pp = AtariPreprocessor(n4, device=local_rank)
+        g = torch.Generator(device="cuda").manual_seed(5 + rank)
+        frames = torch.randint(0, 256, (n4, 2, 210, 160, 3), dtype=torch.uint8, device="cuda", generator=g)
+        pp.reset(frames)
+        for _ in range(5):
+            pp.step(frames)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            pp.step(frames)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        out = torch.empty((n4, 4, 84, 84), dtype=torch.float32, device="cuda")
+        e0.record()
+        for _ in range(steps):
+            pp.stacked_nchw_f32(out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_mat = e0.elapsed_time(e1) / steps
+        pp.close()
+        bps = 2 * 210 * 160 * 3 + 84 * 84
+        return {"value": n4 / (ms * 1e-3), "unit": "env-steps/s (per GPU)", "envs": n4, "kernel_ms": round(ms, 4), "bytes_per_env_step": bps,
+                "achieved_GBs": round(bps * n4 / (ms * 1e-3) / 1e9, 1), "frac": round(bps * n4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "materialize_nchw_f32_ms": round(ms_mat, 4),
+                "materialize_GBs": round((4 * 7056 + 4 * 4 * 7056) * n4 / (ms_mat * 1e-3) / 1e9, 1)}
+
     main_m = measure(args.env, args.mode)
     extra = {}
     if not args.no_extra and args.env == "cartpole" and args.mode == "lockstep":
@@ -152,6 +230,10 @@ def main():
             extra[f"{env}_{mode}"] = {"value": m["value"], "unit": "env-steps/s", "kernel_ms": round(m["kernel_ms"], 4),
                                       "bytes_per_env_step": m["bytes_per_env_step"], "achieved_GBs": round(m["achieved_gbs"], 1),
                                       "frac": round(m["achieved_gbs"] / HBM_PEAK_GBS, 4)}
+        extra["config3_mountaincar_vecnormalize_1M_per_gpu"] = measure_config3(1 << 20, args.steps)
+        extra["config3_mountaincar_vecnormalize_16M_per_gpu"] = measure_config3(1 << 24, max(20, args.steps // 4))
+        if rank == 0:
+            extra["config4_atari_preprocess_4096"] = measure_atari(4096, max(20, args.steps // 4))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

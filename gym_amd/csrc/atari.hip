@@ -30,8 +30,12 @@ using namespace gymhip;
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int kMaxTaps = 1024;  // per axis; 210->84 needs 252, 160->84 needs 244
+constexpr int kBlock = 256;     // elementwise helper kernels
+constexpr int kFrameBlock = 512;  // one workgroup per frame: 8 waves; 4 workgroups (37 KB LDS each) fill a CU's 32 wave slots
+#ifndef GYMHIP_ATARI_WAVES
+#define GYMHIP_ATARI_WAVES 6   // min waves/SIMD: 80 VGPRs -> 3 frames (24 waves) per CU; 4 = 4.67 TB/s, 6 = 5.14, 8 spills = 3.5 (profiles/r01_sweep.txt)
+#endif
+constexpr int kMaxT = 4;        // taps per destination index in the padded tables (zero-weight padding)
 
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \
@@ -39,52 +43,57 @@ constexpr int kMaxTaps = 1024;  // per axis; 210->84 needs 252, 160->84 needs 24
         if (e_ != hipSuccess) return fail(GYMHIP_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-// Per-axis decimation table in per-destination form: taps of dst index d are [ofs[d], ofs[d+1]).
+// Per-axis decimation table, padded to kMaxT taps per destination index.  A padding tap repeats the last source index
+// with weight 0: `acc + S*0.f` is an exact no-op, so the padded sum equals OpenCV's variable-length sum bit for bit.
 struct AxisTable {
-    std::vector<int32_t> ofs;   // dsize + 1
-    std::vector<int32_t> si;    // source index per tap
-    std::vector<float> alpha;   // weight per tap
+    std::vector<int32_t> si;    // [dsize][kMaxT]
+    std::vector<float> alpha;   // [dsize][kMaxT]
+    int max_taps = 0;
 };
 
 // OpenCV computeResizeAreaTab (imgproc/resize.cpp), generic (non-integer-scale) INTER_AREA path; scale = 1/(dsize/ssize).
 AxisTable make_axis_table(int ssize, int dsize) {
     AxisTable t;
     const double scale = 1.0 / ((double)dsize / (double)ssize);
-    t.ofs.push_back(0);
     for (int d = 0; d < dsize; d++) {
+        std::vector<int32_t> si; std::vector<float> al;
         const double f1 = d * scale, f2 = f1 + scale;
         const double cell = std::min(scale, ssize - f1);
         int s1 = (int)std::ceil(f1), s2 = (int)std::floor(f2);
         s2 = std::min(s2, ssize - 1);
         s1 = std::min(s1, s2);
-        if (s1 - f1 > 1e-3) { t.si.push_back(s1 - 1); t.alpha.push_back((float)((s1 - f1) / cell)); }
-        for (int s = s1; s < s2; s++) { t.si.push_back(s); t.alpha.push_back((float)(1.0 / cell)); }
-        if (f2 - s2 > 1e-3) { t.si.push_back(s2); t.alpha.push_back((float)(std::min(std::min(f2 - s2, 1.), cell) / cell)); }
-        t.ofs.push_back((int32_t)t.si.size());
+        if (s1 - f1 > 1e-3) { si.push_back(s1 - 1); al.push_back((float)((s1 - f1) / cell)); }
+        for (int s = s1; s < s2; s++) { si.push_back(s); al.push_back((float)(1.0 / cell)); }
+        if (f2 - s2 > 1e-3) { si.push_back(s2); al.push_back((float)(std::min(std::min(f2 - s2, 1.), cell) / cell)); }
+        t.max_taps = std::max(t.max_taps, (int)si.size());
+        for (int k = 0; k < kMaxT; k++) {
+            const bool real = k < (int)si.size();
+            t.si.push_back(real ? si[k] : (si.empty() ? 0 : si.back()));
+            t.alpha.push_back(real ? al[k] : 0.f);
+        }
     }
     return t;
 }
 
 struct AtariParams {
     const uint8_t* frames;     // u8 [N][2][H][W][3]
-    uint8_t* out;              // plane base: plane of env e starts at out + e * env_stride + slot_offset
-    int64_t env_stride;        // bytes between consecutive envs' destination planes
-    int64_t slot_offset;       // byte offset of the destination plane inside an env's block
+    uint8_t* out;              // plane of env e starts at out + e * env_stride + slot_offset
+    int64_t env_stride;
+    int64_t slot_offset;
     const uint8_t* done;       // u8 [N] or null
     uint8_t* ring;             // ring base (for clear-on-done), or null
-    const int32_t* xofs; const int32_t* xsi; const float* xalpha;
-    const int32_t* yofs; const int32_t* ysi; const float* yalpha;
-    int nxt, nyt;              // tap counts
-    int H, W, dh, dw, n_stack, slot, gray_bits, clear_on_done;
+    const int32_t* xsi; const float* xal;   // [dw][kMaxT]
+    const int32_t* ysi; const float* yal;   // [dh][kMaxT]
+    int H, W, dh, dw, n_stack, slot, clear_on_done;
 };
 
+using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
 __device__ inline uint32_t max_u8x4(uint32_t a, uint32_t b) {
-    // byte-wise unsigned max without widening each byte separately: compare even/odd bytes as 16-bit lanes
+    // byte-wise unsigned max: even and odd bytes widened in place to two 16-bit lanes each -> v_pk_max_u16
     const uint32_t m = 0x00FF00FFu;
-    uint32_t ae = a & m, be = b & m, ao = (a >> 8) & m, bo = (b >> 8) & m;
-    uint32_t e = ((ae & 0xFFFFu) > (be & 0xFFFFu) ? (ae & 0xFFFFu) : (be & 0xFFFFu)) | ((ae >> 16) > (be >> 16) ? (ae & 0xFFFF0000u) : (be & 0xFFFF0000u));
-    uint32_t o = ((ao & 0xFFFFu) > (bo & 0xFFFFu) ? (ao & 0xFFFFu) : (bo & 0xFFFFu)) | ((ao >> 16) > (bo >> 16) ? (ao & 0xFFFF0000u) : (bo & 0xFFFF0000u));
-    return e | (o << 8);
+    const u16x2 e = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a & m), __builtin_bit_cast(u16x2, b & m));
+    const u16x2 o = __builtin_elementwise_max(__builtin_bit_cast(u16x2, (a >> 8) & m), __builtin_bit_cast(u16x2, (b >> 8) & m));
+    return __builtin_bit_cast(uint32_t, e) | (__builtin_bit_cast(uint32_t, o) << 8);
 }
 
 template <int GRAY15>
@@ -100,7 +109,7 @@ __device__ inline uint32_t sat_u8(float v) {   // cv::saturate_cast<uchar>(float
     return (uint32_t)iv;
 }
 
-struct u32x3 { uint32_t x, y, z; };   // 12-B load unit: 4 whole RGB pixels
+struct u32x3 { uint32_t x, y, z; };   // 12-B load unit: 4 whole RGB pixels (the three dword loads merge into one dwordx3)
 __device__ inline u32x3 load_px4(const uint32_t* base, int j) {
     u32x3 v;
     v.x = __builtin_nontemporal_load(base + 3 * j);
@@ -109,21 +118,17 @@ __device__ inline u32x3 load_px4(const uint32_t* base, int j) {
     return v;
 }
 
-template <int GRAY15>
-__global__ __launch_bounds__(kBlock) void atari_preprocess_kernel(const AtariParams p) {
+template <int GRAY15, int NT>
+__global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preprocess_kernel(const AtariParams p) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int HW = p.H * p.W;
     uint8_t* gray = lds;                                           // [H*W] u8
-    int32_t* t_i = (int32_t*)(lds + ((HW + 15) & ~15));            // xofs[dw+1] yofs[dh+1] xsi[nxt] ysi[nyt]
-    int32_t* xofs = t_i; int32_t* yofs = xofs + (p.dw + 1); int32_t* xsi = yofs + (p.dh + 1); int32_t* ysi = xsi + p.nxt;
-    float* xalpha = (float*)(ysi + p.nyt); float* yalpha = xalpha + p.nxt;
+    int32_t* ysi = (int32_t*)(lds + ((HW + 15) & ~15));            // [dh][kMaxT]
+    float* yal = (float*)(ysi + p.dh * kMaxT);                     // [dh][kMaxT]
     const int tid = threadIdx.x;
     const int64_t e = blockIdx.x;
 
-    for (int k = tid; k <= p.dw; k += kBlock) xofs[k] = p.xofs[k];
-    for (int k = tid; k <= p.dh; k += kBlock) yofs[k] = p.yofs[k];
-    for (int k = tid; k < p.nxt; k += kBlock) { xsi[k] = p.xsi[k]; xalpha[k] = p.xalpha[k]; }
-    for (int k = tid; k < p.nyt; k += kBlock) { ysi[k] = p.ysi[k]; yalpha[k] = p.yalpha[k]; }
+    for (int k = tid; k < p.dh * kMaxT; k += kFrameBlock) { ysi[k] = p.ysi[k]; yal[k] = p.yal[k]; }
 
     // ---- phase 1: max of the two frames -> gray -> LDS ---------------------------------------------------------
     const uint32_t* fa = (const uint32_t*)(p.frames + e * 2 * (int64_t)HW * 3);
@@ -131,16 +136,16 @@ __global__ __launch_bounds__(kBlock) void atari_preprocess_kernel(const AtariPar
     const int items = HW / 4;                                      // 4 pixels (12 B) per item
     uint32_t* gray32 = (uint32_t*)gray;
     constexpr int UNR = 4;
-    for (int it = tid; it < items; it += kBlock * UNR) {
+    for (int it = tid; it < items; it += kFrameBlock * UNR) {
         u32x3 a[UNR], b[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
-            const int j = it + u * kBlock;
+            const int j = it + u * kFrameBlock;
             if (j < items) { a[u] = load_px4(fa, j); b[u] = load_px4(fb, j); }
         }
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
-            const int j = it + u * kBlock;
+            const int j = it + u * kFrameBlock;
             if (j >= items) continue;
             const uint32_t w0 = max_u8x4(a[u].x, b[u].x), w1 = max_u8x4(a[u].y, b[u].y), w2 = max_u8x4(a[u].z, b[u].z);
             // bytes: w0 = R0 G0 B0 R1 | w1 = G1 B1 R2 G2 | w2 = B2 R3 G3 B3   (little endian)
@@ -151,27 +156,35 @@ __global__ __launch_bounds__(kBlock) void atari_preprocess_kernel(const AtariPar
             gray32[j] = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
         }
     }
-    __syncthreads();
 
-    // ---- phase 2: INTER_AREA out of LDS, 4 horizontally adjacent outputs per thread -> one 4-B store -------------
-    uint8_t* dst = p.out + e * p.env_stride + p.slot_offset;
-    const int dw4 = p.dw / 4, outs = p.dh * dw4;
-    for (int o = tid; o < outs; o += kBlock) {
-        const int dy = o / dw4, dx0 = (o - dy * dw4) * 4;
-        float sum[4] = {0.f, 0.f, 0.f, 0.f};
-        const int y0 = yofs[dy], y1 = yofs[dy + 1];
-        for (int j = y0; j < y1; j++) {
-            const float beta = yalpha[j];
-            const uint8_t* S = gray + ysi[j] * p.W;
+    // ---- phase 2: INTER_AREA out of LDS.  A thread owns 4 horizontally adjacent output columns (its 4 x NT x-taps stay
+    // in registers) and walks down the rows; the 4 results leave as one 4-B store. -----------------------------------------
+    const int dw4 = p.dw / 4, rows_per_pass = kFrameBlock / dw4;
+    const int qx = tid % dw4, ry = tid / dw4;
+    int xs[4][NT]; float xa[4][NT];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                float buf = 0.f;
-                for (int k = xofs[dx0 + q]; k < xofs[dx0 + q + 1]; k++) buf += (float)S[xsi[k]] * xalpha[k];
-                sum[q] = (j == y0) ? beta * buf : sum[q] + beta * buf;
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int k = 0; k < NT; k++) { xs[q][k] = p.xsi[(qx * 4 + q) * kMaxT + k]; xa[q][k] = p.xal[(qx * 4 + q) * kMaxT + k]; }
+    __syncthreads();
+    uint32_t* dst32 = (uint32_t*)(p.out + e * p.env_stride + p.slot_offset);
+    if (ry < rows_per_pass) {
+        for (int dy = ry; dy < p.dh; dy += rows_per_pass) {
+            float sum[4];
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const float beta = yal[dy * kMaxT + j];
+                const uint8_t* S = gray + ysi[dy * kMaxT + j] * p.W;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float buf = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NT; k++) buf += (float)S[xs[q][k]] * xa[q][k];
+                    sum[q] = (j == 0) ? beta * buf : sum[q] + beta * buf;
+                }
             }
+            dst32[dy * dw4 + qx] = sat_u8(sum[0]) | (sat_u8(sum[1]) << 8) | (sat_u8(sum[2]) << 16) | (sat_u8(sum[3]) << 24);
         }
-        const uint32_t packed = sat_u8(sum[0]) | (sat_u8(sum[1]) << 8) | (sat_u8(sum[2]) << 16) | (sat_u8(sum[3]) << 24);
-        ((uint32_t*)dst)[o] = packed;
     }
 
     // ---- optional SB3-style clear of the older planes when the env finished an episode --------------------------
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void atari_preprocess_kernel(const AtariPar
         for (int s = 0; s < p.n_stack; s++) {
             if (s == p.slot) continue;
             uint32_t* pl = (uint32_t*)(p.ring + (e * p.n_stack + s) * (int64_t)(p.dh * p.dw));
-            for (int k = tid; k < plane4; k += kBlock) pl[k] = 0u;
+            for (int k = tid; k < plane4; k += kFrameBlock) pl[k] = 0u;
         }
     }
 }
@@ -240,9 +253,9 @@ struct gymhip_atari {
     int device;
     uint8_t* ring;        // u8 [N][k][dh*dw]
     int head;             // slot of the newest frame
-    int32_t *xofs, *xsi, *yofs, *ysi;
-    float *xalpha, *yalpha;
-    int nxt, nyt;
+    int32_t *xsi, *ysi;   // padded tap tables [dst][kMaxT]
+    float *xal, *yal;
+    int max_taps;
     size_t lds_bytes;
     bool did_reset;
 };
@@ -269,13 +282,18 @@ int launch_preprocess(gymhip_atari* h, const uint8_t* frames, uint8_t* out, int6
     AtariParams p{};
     p.frames = frames; p.out = out; p.env_stride = env_stride; p.slot_offset = slot_offset;
     p.done = done; p.ring = ring_dst ? h->ring : nullptr;
-    p.xofs = h->xofs; p.xsi = h->xsi; p.xalpha = h->xalpha; p.yofs = h->yofs; p.ysi = h->ysi; p.yalpha = h->yalpha;
-    p.nxt = h->nxt; p.nyt = h->nyt;
+    p.xsi = h->xsi; p.xal = h->xal; p.ysi = h->ysi; p.yal = h->yal;
     p.H = h->cfg.src_h; p.W = h->cfg.src_w; p.dh = h->cfg.dst_h; p.dw = h->cfg.dst_w;
-    p.n_stack = h->cfg.n_stack; p.slot = h->head; p.gray_bits = h->cfg.gray_bits; p.clear_on_done = h->cfg.clear_on_done;
-    dim3 grid((unsigned)h->cfg.n_envs), block(kBlock);
-    if (h->cfg.gray_bits == 15) hipLaunchKernelGGL(atari_preprocess_kernel<1>, grid, block, h->lds_bytes, s, p);
-    else hipLaunchKernelGGL(atari_preprocess_kernel<0>, grid, block, h->lds_bytes, s, p);
+    p.n_stack = h->cfg.n_stack; p.slot = h->head; p.clear_on_done = h->cfg.clear_on_done;
+    dim3 grid((unsigned)h->cfg.n_envs), block(kFrameBlock);
+    const bool g15 = h->cfg.gray_bits == 15;
+    if (h->max_taps <= 3) {
+        if (g15) hipLaunchKernelGGL((atari_preprocess_kernel<1, 3>), grid, block, h->lds_bytes, s, p);
+        else hipLaunchKernelGGL((atari_preprocess_kernel<0, 3>), grid, block, h->lds_bytes, s, p);
+    } else {
+        if (g15) hipLaunchKernelGGL((atari_preprocess_kernel<1, 4>), grid, block, h->lds_bytes, s, p);
+        else hipLaunchKernelGGL((atari_preprocess_kernel<0, 4>), grid, block, h->lds_bytes, s, p);
+    }
     HIP_TRY(hipGetLastError());
     return GYMHIP_OK;
 }
@@ -299,22 +317,21 @@ int gymhip_atari_create(const gymhip_atari_config* cfg, int device, gymhip_atari
     if (device < 0 || device >= ndev) return fail(GYMHIP_EINVAL, "device %d out of range (%d visible)", device, ndev);
     HIP_TRY(hipSetDevice(device));
     AxisTable xt = make_axis_table(cfg->src_w, cfg->dst_w), yt = make_axis_table(cfg->src_h, cfg->dst_h);
-    if ((int)xt.si.size() > kMaxTaps || (int)yt.si.size() > kMaxTaps) return fail(GYMHIP_EINVAL, "decimation table too large");
+    if (xt.max_taps > kMaxT || yt.max_taps > kMaxT) return fail(GYMHIP_EINVAL, "scale factors above 3 need more than %d taps per output: not supported", kMaxT);
+    if (cfg->dst_w / 4 > kFrameBlock) return fail(GYMHIP_EINVAL, "dst_w too large for one workgroup per frame");
     gymhip_atari* h = new (std::nothrow) gymhip_atari();
     if (!h) return fail(GYMHIP_EINVAL, "out of host memory");
     std::memset(h, 0, sizeof *h);
     h->cfg = *cfg; h->device = device; h->head = 0; h->did_reset = false;
-    h->nxt = (int)xt.si.size(); h->nyt = (int)yt.si.size();
+    h->max_taps = std::max(xt.max_taps, yt.max_taps);
     const size_t hw = (size_t)cfg->src_h * cfg->src_w;
-    h->lds_bytes = ((hw + 15) & ~(size_t)15) + sizeof(int32_t) * (cfg->dst_w + 1 + cfg->dst_h + 1 + h->nxt + h->nyt) + sizeof(float) * (h->nxt + h->nyt);
+    h->lds_bytes = ((hw + 15) & ~(size_t)15) + (sizeof(int32_t) + sizeof(float)) * cfg->dst_h * kMaxT;
     int rc = GYMHIP_OK;
     if (h->lds_bytes > 160 * 1024) rc = fail(GYMHIP_EINVAL, "gray frame + tables (%zu B) exceed the 160 KiB LDS of a CU", h->lds_bytes);
-    if (!rc) rc = upload(xt.ofs, &h->xofs);
     if (!rc) rc = upload(xt.si, &h->xsi);
-    if (!rc) rc = upload(xt.alpha, &h->xalpha);
-    if (!rc) rc = upload(yt.ofs, &h->yofs);
+    if (!rc) rc = upload(xt.alpha, &h->xal);
     if (!rc) rc = upload(yt.si, &h->ysi);
-    if (!rc) rc = upload(yt.alpha, &h->yalpha);
+    if (!rc) rc = upload(yt.alpha, &h->yal);
     if (!rc) {
         void* p = nullptr;
         const size_t bytes = (size_t)cfg->n_envs * cfg->n_stack * cfg->dst_h * cfg->dst_w;
@@ -324,9 +341,11 @@ int gymhip_atari_create(const gymhip_atari_config* cfg, int device, gymhip_atari
         h->ring = (uint8_t*)p;
     }
     if (!rc && h->lds_bytes > 64 * 1024) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)atari_preprocess_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        hipError_t e0 = hipFuncSetAttribute((const void*)atari_preprocess_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        if (e1 != hipSuccess || e0 != hipSuccess) rc = fail(GYMHIP_EHIP, "cannot raise the dynamic LDS limit to %zu B", h->lds_bytes);
+        const void* fns[] = {(const void*)atari_preprocess_kernel<1, 3>, (const void*)atari_preprocess_kernel<0, 3>,
+                             (const void*)atari_preprocess_kernel<1, 4>, (const void*)atari_preprocess_kernel<0, 4>};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess)
+                rc = fail(GYMHIP_EHIP, "cannot raise the dynamic LDS limit to %zu B", h->lds_bytes);
     }
     if (rc) { gymhip_atari_destroy(h); return rc; }
     *out = h;
@@ -337,7 +356,7 @@ int gymhip_atari_destroy(gymhip_atari* h) {
     if (!h) return GYMHIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {h->ring, h->xofs, h->xsi, h->xalpha, h->yofs, h->ysi, h->yalpha};
+    void* ptrs[] = {h->ring, h->xsi, h->xal, h->ysi, h->yal};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return GYMHIP_OK;
