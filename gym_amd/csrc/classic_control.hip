@@ -16,8 +16,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
+#include <random>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "gymhip.h"
 #include "gymhip_internal.h"
@@ -898,6 +902,42 @@ int gymhip_upload_reset_tape(gymhip_engine* h, const float* host_tape, int64_t e
     if (!host_tape) return fail(GYMHIP_EINVAL, "host_tape is null");
     if (int rc = ensure_tape(h, episodes)) return rc;
     HIP_TRY(hipMemcpy(h->tape, host_tape, (size_t)episodes * h->cfg.n_envs * 16, hipMemcpyHostToDevice));
+    return GYMHIP_OK;
+}
+
+static int draw_reset_tape(gymhip_engine* h, bool seeded, uint64_t seed, int64_t episodes);
+int gymhip_seed_reset_tape(gymhip_engine* h, uint64_t seed, int64_t episodes) { return draw_reset_tape(h, true, seed, episodes); }
+int gymhip_unseeded_reset_tape(gymhip_engine* h, int64_t episodes) { return draw_reset_tape(h, false, 0, episodes); }
+static int draw_reset_tape(gymhip_engine* h, bool seeded, uint64_t seed, int64_t episodes) {
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = ensure_tape(h, episodes)) return rc;
+    // The reference's own generator, called the way it calls it: env i owns std::mt19937 seeded `seed + i`
+    // (sync_env.h:74-83 -> env.h:60-63 / cartpole.h:24-26) and every reset draws four
+    // std::uniform_real_distribution<float>(-0.05f, 0.05f) values in order (cartpole.cpp:21-26).
+    const int64_t n = h->cfg.n_envs;
+    std::vector<float> tape;
+    try { tape.resize((size_t)episodes * n * 4); } catch (...) { return fail(GYMHIP_EINVAL, "out of host memory for the reset tape"); }
+    unsigned hw = std::thread::hardware_concurrency();
+    const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(hw ? hw : 1), 32, n / 1024 + 1}));
+    std::vector<std::thread> pool;
+    float* out = tape.data();
+    const int64_t off = h->cfg.env_offset;
+    for (int t = 0; t < n_thr; t++) {
+        pool.emplace_back([=]() {
+            for (int64_t i = t; i < n; i += n_thr) {
+                std::mt19937 dev;   // default-constructed (5489) when the caller never seeded: all envs share one stream (env.h:83)
+                if (seeded) dev.seed(seed + (uint64_t)(off + i));
+                for (int64_t k = 0; k < episodes; k++) {
+                    std::uniform_real_distribution<float> dist(-0.05f, 0.05f);
+                    float* row = out + (k * n + i) * 4;
+                    row[0] = dist(dev); row[1] = dist(dev); row[2] = dist(dev); row[3] = dist(dev);
+                }
+            }
+        });
+    }
+    for (auto& th : pool) th.join();
+    if (seeded) h->cfg.seed = seed;
+    HIP_TRY(hipMemcpy(h->tape, tape.data(), tape.size() * sizeof(float), hipMemcpyHostToDevice));
     return GYMHIP_OK;
 }
 

@@ -110,6 +110,13 @@ class Engine:
         assert tape.ndim == 3 and tape.shape[1:] == (self.cfg.n_envs, 4), tape.shape
         L.check(self.lib.gymhip_upload_reset_tape(self.h, tape.ctypes.data_as(C.c_void_p), tape.shape[0]), "gymhip_upload_reset_tape")
 
+    def seed_reset_tape(self, seed: int, episodes: int):
+        """VecEnv::seed for TAPE mode: the library draws the tape with std::mt19937(seed + env_offset + i) on the host."""
+        L.check(self.lib.gymhip_seed_reset_tape(self.h, seed, episodes), "gymhip_seed_reset_tape")
+
+    def seed_reset_tape_unseeded(self, episodes: int):
+        L.check(self.lib.gymhip_unseeded_reset_tape(self.h, episodes), "gymhip_unseeded_reset_tape")
+
     def generate_reset_tape(self, episodes: int):
         L.check(self.lib.gymhip_generate_reset_tape(self.h, episodes, self._stream()), "gymhip_generate_reset_tape")
 

@@ -1,0 +1,313 @@
+"""Host-side mirror of the reference's vectorised-env interface for the hot path.
+
+Same names, argument meaning and error behaviour as the C++ templates it stands in for:
+
+    gym::VecEnv<false>                 wrappers/vec_env/base.h:30-79
+    gym::VecEnvWrapper<false>          wrappers/vec_env/vec_env_wrapper.h:12-55
+    gym::SyncVecEnv<Monitor<ClipRewardEnv<TimeLimit<Env>>>>   wrappers/vec_env/sync_env.h  -> HipVecEnv
+    gym::VecNormalize<false, training, normReward, normObs>   wrappers/vec_env/vec_normalize.h -> VecNormalize
+    gym::VecFrameStack / VecNormAndPermute                     vec_frame_stack.cpp, vec_atari.cpp -> gym_amd.atari
+
+The per-env wrappers are not objects here: TimeLimit / ClipReward / Monitor (and VecNormalize) are flags of ONE fused
+kernel.  Returned tensors are views of device buffers that the next step overwrites (the reference allocates fresh
+tensors every step, sync_env.h:107-112) — clone what you keep.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import NamedTuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import spaces
+from .engine import Engine, EngineConfig
+
+_ENV_IDS = {"CartPole": L.ENV_CARTPOLE, "CartPole-v1": L.ENV_CARTPOLE, "MountainCar": L.ENV_MOUNTAINCAR, "MountainCar-v0": L.ENV_MOUNTAINCAR}
+
+
+class VecEnvStepReturn(NamedTuple):
+    """base.h:18-25: observation [N, F] f32, reward [N, 1] f32, done [N, 1] f32 (0/1), info (one map per env)."""
+    observation: torch.Tensor
+    reward: torch.Tensor
+    done: torch.Tensor
+    info: "LazyInfos"
+
+
+class LazyInfos:
+    """vector<AnyMap> info (base.h:24) built on demand: N unordered_maps per step are the reference's host bottleneck at
+    large N, so maps are materialised only when indexed, and only finished envs have entries:
+    info[i]["episode"] = {"r", "l", "t"} (monitor.h:86-97), info[i]["TimeLimit.truncated"] (time_limit.h:32)."""
+
+    def __init__(self, venv: "HipVecEnv"):
+        self._venv = venv
+        self._host = None
+
+    def __len__(self):
+        return self._venv.numEnvs
+
+    def _fetch(self):
+        if self._host is None:
+            v = self._venv
+            ln, tr, ret = v.engine.episode_info()
+            done = v.engine.done
+            self._host = dict(done=done.cpu().numpy() != 0, length=ln.cpu().numpy(), truncated=tr.cpu().numpy() != 0, ret=ret.cpu().numpy(),
+                              t=time.perf_counter() - v._t_start)
+        return self._host
+
+    def done_indices(self):
+        return np.nonzero(self._fetch()["done"])[0]
+
+    def __getitem__(self, i):
+        h = self._fetch()
+        if i < 0 or i >= len(self):
+            raise IndexError(i)
+        if not h["done"][i]:
+            return {}
+        d = {}
+        v = self._venv
+        if v._wrappers & L.WRAP_TIME_LIMIT:
+            d["TimeLimit.truncated"] = bool(h["truncated"][i])
+        if v._wrappers & L.WRAP_MONITOR:
+            d["episode"] = {"r": float(h["ret"][i]), "l": float(h["length"][i]), "t": h["t"]}
+        return d
+
+
+class VecEnv:
+    """gym::VecEnv<false> (base.h:30-79)."""
+
+    def __init__(self, numEnvs: int, o_space, a_space):
+        self.numEnvs = int(numEnvs)
+        self._o_space, self._a_space = o_space, a_space
+
+    def actionSpace(self):
+        return self._a_space
+
+    def observationSpace(self):
+        return self._o_space
+
+    def nEnvs(self):
+        return self.numEnvs
+
+    def reset(self, index=None):
+        raise NotImplementedError
+
+    def stepAsync(self, actions):
+        raise NotImplementedError
+
+    def stepWait(self) -> VecEnvStepReturn:
+        raise NotImplementedError
+
+    def step(self, actions) -> VecEnvStepReturn:   # base.h:60-63
+        self.stepAsync(actions)
+        return self.stepWait()
+
+    def isWrapper(self):
+        return False
+
+    def render(self):
+        raise NotImplementedError("rendering is outside the batched engine (SURVEY.md §2 row 35)")
+
+    def seed(self, _seed: int):
+        return []
+
+
+def shard_range(n_global: int, rank: int, world: int):
+    """GPU g of G owns the contiguous env range [g*N/G, (g+1)*N/G); seeds follow the GLOBAL index."""
+    lo = (n_global * rank) // world
+    hi = (n_global * (rank + 1)) // world
+    return lo, hi
+
+
+class HipVecEnv(VecEnv):
+    """Drop-in for SyncVecEnv over N CartPole / MountainCar envs with their per-env wrapper chain, on one MI355X.
+
+    `n_envs` is the GLOBAL env count; with `world` > 1 this process holds shard `rank` of it (one process per GPU) and
+    env i is still seeded `seed + i` with i the global index, so results do not depend on the GPU count.
+    """
+
+    def __init__(self, env_id: str, n_envs: int, max_episode_steps: int | None = None, clip_reward: bool = False, monitor: bool = True,
+                 lockstep: bool = True, reset_mode: str = "tape", tape_episodes: int = 2048, device: int | None = None,
+                 rank: int | None = None, world: int | None = None, process_group=None, auto_reset: bool = True):
+        if env_id not in _ENV_IDS:
+            raise ValueError(f"unknown env id {env_id!r}; the engine implements {sorted(_ENV_IDS)}")
+        if not auto_reset:
+            raise ValueError("the fused kernel always auto-resets (SyncVecEnv's default, sync_env.h:28,92); auto_reset=False is not implemented")
+        self.kind = _ENV_IDS[env_id]
+        self.rank = int(os.environ.get("RANK", 0)) if rank is None else rank
+        self.world = int(os.environ.get("WORLD_SIZE", 1)) if world is None else world
+        self.group = process_group
+        self.n_global = int(n_envs)
+        lo, hi = shard_range(self.n_global, self.rank, self.world)
+        o_space, a_space = spaces.cartpole_spaces() if self.kind == L.ENV_CARTPOLE else spaces.mountaincar_spaces()
+        super().__init__(hi - lo, o_space, a_space)
+        self.env_offset = lo
+        self._wrappers = (L.WRAP_TIME_LIMIT if max_episode_steps else 0) | (L.WRAP_CLIP_REWARD if clip_reward else 0) | (L.WRAP_MONITOR if monitor else 0)
+        self._max_steps = int(max_episode_steps or 0)
+        self._lockstep = lockstep
+        self._reset_mode = L.RESET_TAPE if (reset_mode == "tape" and self.kind == L.ENV_CARTPOLE) else L.RESET_COUNTER_RNG
+        self._tape_episodes = tape_episodes
+        self._device = int(os.environ.get("LOCAL_RANK", 0)) if device is None else device
+        self._norm = None          # set by VecNormalize before the engine exists
+        self._seed = None          # unseeded envs keep default-constructed mt19937 (seed 5489) — identical streams
+        self.engine: Engine | None = None
+        self._actions = None
+        self._t_start = time.perf_counter()
+
+    @staticmethod
+    def make(*args, **kw):   # factory idiom of the reference (sync_env.h:62-64)
+        return HipVecEnv(*args, **kw)
+
+    # -- engine construction is deferred so that VecNormalize can fuse itself in -------------------------------
+    def _ensure_engine(self):
+        if self.engine is not None:
+            return
+        w = self._wrappers
+        kw = {}
+        if self._norm is not None:
+            nm = self._norm
+            w |= (L.WRAP_NORM_OBS if nm["norm_obs"] else 0) | (L.WRAP_NORM_REWARD if nm["norm_reward"] else 0) | (L.WRAP_NORM_TRAINING if nm["training"] else 0)
+            kw = dict(clip_obs=nm["clip_obs"], clip_reward=nm["clip_reward"], gamma=nm["gamma"], epsilon=nm["epsilon"])
+        cfg = EngineConfig(env_kind=self.kind, n_envs=self.numEnvs, precision=L.PRECISION_LOCKSTEP_F64 if self._lockstep else L.PRECISION_F32,
+                           reset_mode=self._reset_mode, wrappers=w, max_episode_steps=self._max_steps, env_offset=self.env_offset,
+                           seed=self._seed if self._seed is not None else 0, **kw)
+        self.engine = Engine(cfg, self._device)
+        if self._reset_mode == L.RESET_TAPE:
+            if self._seed is None:
+                # every unseeded reference env draws from the same default stream: one row set, replicated
+                self.engine.seed_reset_tape_unseeded(self._tape_episodes)
+            else:
+                self.engine.seed_reset_tape(self._seed, self._tape_episodes)
+
+    def _has_norm(self):
+        return self._norm is not None and (self._norm["norm_obs"] or self._norm["norm_reward"])
+
+    def _allreduce_moments(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.engine.moments, group=self.group)   # RCCL: 2F+6 doubles, latency-bound
+
+    # -- VecEnv interface ------------------------------------------------------------------------------------------
+    def seed(self, _seed: int):
+        """sync_env.h:74-83: env i <- _seed + i; returns the per-env seeds of this shard."""
+        if self.engine is not None:
+            raise RuntimeError("seed() must precede the first reset(): the reset tape is drawn from it")
+        self._seed = int(_seed)
+        return [self._seed + self.env_offset + i for i in range(self.numEnvs)] if self.numEnvs <= 1 << 20 else range(
+            self._seed + self.env_offset, self._seed + self.env_offset + self.numEnvs)
+
+    def reset(self, index=None):
+        if index is not None:
+            raise NotImplementedError("reset(int index): per-index paths are a 'next' row (SURVEY.md §8f.2)")
+        self._ensure_engine()
+        e = self.engine
+        e.reset_begin()
+        if self._has_norm():
+            self._allreduce_moments()
+        e.reset_finish()
+        return e.obs_norm if (self._norm and self._norm["norm_obs"]) else e.obs
+
+    def stepAsync(self, actions):
+        self._actions = actions   # tensor_adapter.cpp:22-23: decoded to int32 at launch if not already an integer device tensor
+
+    def stepWait(self) -> VecEnvStepReturn:
+        if self.engine is None:
+            raise RuntimeError("stepWait() before reset()")
+        if self._actions is None:
+            raise RuntimeError("stepWait() without stepAsync()")
+        e = self.engine
+        e.step_begin(self._actions)
+        if self._has_norm():
+            self._allreduce_moments()
+        e.step_finish()
+        self._actions = None
+        obs = e.obs_norm if (self._norm and self._norm["norm_obs"]) else e.obs
+        return VecEnvStepReturn(obs, e.reward.view(-1, 1), e.done.view(-1, 1), LazyInfos(self))
+
+    def episode_statistics(self):
+        """(episodes, sum of returns, sum of lengths) over ALL shards — Monitor getters in aggregate (monitor.h:104-107)."""
+        tot = torch.from_numpy(self.engine.episode_stats()).to(self.engine.device)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(tot, group=self.group)
+        return tot.cpu().numpy()
+
+
+class VecEnvWrapper(VecEnv):
+    """gym::VecEnvWrapper<false> (vec_env_wrapper.h:12-55): forwards everything to `venv`."""
+
+    def __init__(self, venv: VecEnv, o_space=None, a_space=None):
+        super().__init__(venv.nEnvs(), o_space or venv.observationSpace(), a_space or venv.actionSpace())
+        self.venv = venv
+
+    def isWrapper(self):
+        return True
+
+    def reset(self, index=None):
+        return self.venv.reset(index)
+
+    def stepAsync(self, actions):
+        self.venv.stepAsync(actions)
+
+    def stepWait(self):
+        return self.venv.stepWait()
+
+    def seed(self, _seed):
+        return self.venv.seed(_seed)
+
+
+class VecNormalize(VecEnvWrapper):
+    """gym::VecNormalize<false, isTraining, normReward, normObs> (vec_normalize.h:20-232); TrainingVecNormRO =
+    VecNormalize(venv) with the defaults (gym_.h:15-16).  Must wrap a HipVecEnv before its first reset: the
+    normaliser runs inside the env's own kernels."""
+
+    def __init__(self, venv: HipVecEnv, clip_obs: float = 10.0, clip_reward: float = 10.0, gamma: float = 0.99, epsilon: float = 1e-8,
+                 training: bool = True, norm_reward: bool = True, norm_obs: bool = True):
+        if not isinstance(venv, HipVecEnv):
+            raise TypeError("VecNormalize fuses into a HipVecEnv; got " + type(venv).__name__)
+        if venv.engine is not None:
+            raise RuntimeError("wrap the HipVecEnv in VecNormalize before its first reset()")
+        super().__init__(venv)
+        venv._norm = dict(clip_obs=clip_obs, clip_reward=clip_reward, gamma=gamma, epsilon=epsilon, training=training,
+                          norm_reward=norm_reward, norm_obs=norm_obs)
+
+    def oldObs(self):
+        """vec_normalize.h:94: the un-normalised observations of the last reset/step."""
+        return self.venv.engine.obs
+
+    def get(self):
+        """vec_normalize.h:75-77: (obs RMS, return RMS) as dicts of mean / m_Var / m_Count (running_mean_std.h:17-19)."""
+        s = self.venv.engine.get_norm_stats()
+        F = self.venv.engine.F
+        return (dict(mean=s[:F].copy(), m_Var=s[F:2 * F].copy(), m_Count=float(s[2 * F])),
+                dict(mean=float(s[2 * F + 1]), m_Var=float(s[2 * F + 2]), m_Count=float(s[2 * F + 3])))
+
+    def save(self, path):
+        """vec_normalize.h:79-92: returns.pt + observation.pt, each {mean, m_Var, m_Count} (running_mean_std.h:28-33)."""
+        os.makedirs(path, exist_ok=True)
+        obs, ret = self.get()
+        if self.venv._norm["norm_reward"]:
+            torch.save({k: torch.as_tensor(v, dtype=torch.float32) for k, v in ret.items()}, os.path.join(path, "returns.pt"))
+        if self.venv._norm["norm_obs"]:
+            torch.save({k: torch.as_tensor(v, dtype=torch.float32) for k, v in obs.items()}, os.path.join(path, "observation.pt"))
+
+    def load(self, path):
+        """vec_normalize.h:96-108."""
+        self.venv._ensure_engine()
+        e = self.venv.engine
+        s = e.get_norm_stats()
+        F = e.F
+        if self.venv._norm["norm_reward"]:
+            r = torch.load(os.path.join(path, "returns.pt"), weights_only=True)
+            s[2 * F + 1], s[2 * F + 2], s[2 * F + 3] = float(r["mean"]), float(r["m_Var"]), float(r["m_Count"])
+        if self.venv._norm["norm_obs"]:
+            o = torch.load(os.path.join(path, "observation.pt"), weights_only=True)
+            s[:F], s[F:2 * F], s[2 * F] = o["mean"].numpy(), o["m_Var"].numpy(), float(o["m_Count"])
+        e.set_norm_stats(s)
+
+
+def TrainingVecNormRO(venv: HipVecEnv) -> VecNormalize:
+    """gym_.h:15-16."""
+    return VecNormalize(venv, training=True, norm_reward=True, norm_obs=True)

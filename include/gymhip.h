@@ -104,6 +104,13 @@ int gymhip_seed(gymhip_engine* h, uint64_t seed);
 /* Host-drawn reset tape f32 [episodes][n_envs][4] (CartPole; cartpole.cpp:19-31 + env.h:60-68 semantics), copied to the
  * device.  MountainCar resets are deterministic (mountain_car.cpp:38-42) and need no tape. */
 int gymhip_upload_reset_tape(gymhip_engine* h, const float* host_tape, int64_t episodes);
+/* VecEnv::seed(seed) for TAPE mode (sync_env.h:74-83): draws the tape ON THE HOST with std::mt19937(seed + env_offset + i)
+ * and std::uniform_real_distribution<float>(-0.05f, 0.05f) — the reference's own generator, 4 draws per reset in order
+ * (cartpole.cpp:21-26) — for `episodes` resets per env, and uploads it.  Call before gymhip_reset(). */
+int gymhip_seed_reset_tape(gymhip_engine* h, uint64_t seed, int64_t episodes);
+/* The same for envs that were never seeded: each keeps a default-constructed std::mt19937 (env.h:83), so — exactly as
+ * in the reference — every env replays the same stream. */
+int gymhip_unseeded_reset_tape(gymhip_engine* h, int64_t episodes);
 /* Fill a device-resident tape of `episodes` rows with the COUNTER_RNG generator (bench / throughput set-up). */
 int gymhip_generate_reset_tape(gymhip_engine* h, int64_t episodes, void* stream);
 /* Copy the device tape back (tests: lets the CPU oracle replay a device-generated tape). */

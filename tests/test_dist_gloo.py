@@ -1,0 +1,90 @@
+"""CPU, world_size 2 over gloo (standing in for RCCL): the sharded normaliser reduction.
+
+Each rank owns half of the envs (gym_amd.vec_env.shard_range), builds the moments payload of its shard
+(gym_amd.moments.local_moments — the numpy mirror of step_kernel + reduce_partials_kernel), all-reduces it with the same
+torch.distributed call HipVecEnv uses, and applies the float32 update (mirror of normalize_kernel).  The result must
+track the oracle's single-process VecNormalize over ALL envs: running statistics to 1e-5, identical on both ranks, and
+independent of the GPU count."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, T, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gym_amd import moments as M
+    from gym_amd.vec_env import shard_range
+    from tests.oracle_lib import MOUNTAINCAR, F_CLIP_REWARD, F_MONITOR, F_TIME_LIMIT, Oracle, splitmix_actions
+    o = Oracle()
+    lo, hi = shard_range(n, rank, world)
+    shard = o.vec(MOUNTAINCAR, hi - lo, F_TIME_LIMIT | F_CLIP_REWARD | F_MONITOR, 200, threads=1)   # raw env outputs of this shard
+    F, gamma = 2, np.float32(0.99)
+    stats = M.initial_stats(F)
+    returns = np.zeros(hi - lo, np.float32)
+
+    def allreduce(m):
+        t = torch.from_numpy(m)
+        dist.all_reduce(t)            # the call HipVecEnv._allreduce_moments makes on the device payload
+        return t.numpy()
+
+    obs = shard.reset()
+    stats = M.apply_moments(stats, allreduce(M.local_moments(obs, None, stats)), F, update_obs=True, update_ret=False)
+    acts = splitmix_actions(5, T, n, 3)[:, lo:hi]
+    hist = [stats.copy()]
+    episodes = 0.0
+    for t in range(T):
+        r = shard.step(acts[t])
+        returns = (returns * gamma + r["reward"]).astype(np.float32)
+        d = r["done"] != 0
+        m = allreduce(M.local_moments(r["obs"], returns, stats, ep=(d.sum(), r["ep_r"][d].sum(), r["ep_l"][d].sum())))
+        assert m[0] == n
+        episodes += m[3 + 2 * F]
+        stats = M.apply_moments(stats, m, F)
+        returns[d] = 0
+        hist.append(stats.copy())
+    np.save(os.path.join(out_dir, f"stats_{world}_{rank}.npy"), np.stack(hist))
+    np.save(os.path.join(out_dir, f"episodes_{world}_{rank}.npy"), np.array([episodes]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_normaliser_moments_world2(tmp_path, oracle):
+    from tests.oracle_lib import MOUNTAINCAR, F_CLIP_REWARD, F_MONITOR, F_TIME_LIMIT, splitmix_actions
+    n, T = 4096, 230
+    for world in (1, 2):
+        mp.spawn(_worker, args=(world, _free_port(), n, T, str(tmp_path)), nprocs=world, join=True)
+    full = oracle.vec(MOUNTAINCAR, n, F_TIME_LIMIT | F_CLIP_REWARD | F_MONITOR, 200)
+    full.attach_norm()
+    full.norm_reset()
+    want = [full.norm_stats()]
+    acts = splitmix_actions(5, T, n, 3)
+    eps = 0
+    for t in range(T):
+        eps += int((full.norm_step(acts[t])["done"] != 0).sum())
+        want.append(full.norm_stats())
+    want = np.stack(want)
+    r0, r1 = np.load(tmp_path / "stats_2_0.npy"), np.load(tmp_path / "stats_2_1.npy")
+    one = np.load(tmp_path / "stats_1_0.npy")
+    assert np.array_equal(r0, r1)                                           # replicated statistics never drift apart
+    err = np.abs(r0 - want) / np.maximum(np.abs(want), 1e-6)
+    assert err.max() <= 1e-5, err.max()
+    assert (np.abs(r0 - one) <= 1e-6 * np.maximum(np.abs(one), 1e-6)).all()  # independent of the number of shards
+    assert np.load(tmp_path / "episodes_2_0.npy")[0] == eps == np.load(tmp_path / "episodes_1_0.npy")[0]

@@ -1,0 +1,69 @@
+"""CPU: host-side mirror of the reference interface (spaces, VecEnv plumbing, sharding rule, counter-word layout)."""
+import re
+import os
+
+import numpy as np
+import pytest
+
+from gym_amd import spaces
+from gym_amd import vec_env as V
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_spaces_mirror_reference():
+    o, a = spaces.cartpole_spaces()
+    assert o.size() == [4] and o.type() == np.float32 and a.n == 2                      # cartpole.cpp:10-16
+    r = o.getRange()
+    assert r[0].high == float(np.float32(2.4) * 2) and r[1].high == spaces.FLT_MAX and abs(r[2].high - 0.41887903) < 1e-7
+    assert [x.low for x in r] == [-x.high for x in r]
+    o2, a2 = spaces.mountaincar_spaces()
+    assert o2.size() == [2] and a2.n == 3 and len(o2.getRange()) == 1                    # mountain_car.cpp:11-12
+    assert o2.getRange()[0].low == spaces.FLT_MIN > 0                                  # numeric_limits<float>::min() quirk
+    assert a.as_(spaces.Discrete) is a and a.as_(spaces.Box) is None                    # space.h:72-74
+    assert all(0 <= a2.sample() < 3 for _ in range(50))
+    with pytest.raises(ValueError):
+        spaces.Discrete(0)                                                             # discrete.cpp:19-20
+    with pytest.raises(ValueError):
+        spaces.makeBoxSpace([0.0, 1.0], [1.0], 2)                                      # box.tpp:10-17
+    c = o.clone()
+    assert c is not o and c.size() == o.size()
+    img = spaces.makeBoxSpace(0, 255, [84, 84, 1], dtype=np.uint8)                     # warp_frame.h:28
+    assert img.size() == [84, 84, 1] and img.type() == np.uint8
+
+
+def test_shard_range_partitions_exactly():
+    for n in (1, 7, 65536, 1048576, 1000003):
+        for world in (1, 2, 3, 8):
+            parts = [V.shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_hipvecenv_host_logic_without_gpu():
+    v = V.HipVecEnv("CartPole-v1", 1000, max_episode_steps=500, rank=1, world=4)
+    assert v.nEnvs() == 250 and v.env_offset == 250
+    assert v.seed(7)[:3] == [257, 258, 259]                                           # sync_env.h:74-83 on the global index
+    assert v.actionSpace().n == 2 and v.observationSpace().size() == [4]
+    with pytest.raises(RuntimeError, match="before reset"):
+        v.stepWait()
+    with pytest.raises(ValueError):
+        V.HipVecEnv("LunarLander", 4)
+    with pytest.raises(ValueError):
+        V.HipVecEnv("CartPole", 4, auto_reset=False)
+    with pytest.raises(TypeError):
+        V.VecNormalize(object())
+    w = V.TrainingVecNormRO(V.HipVecEnv("MountainCar-v0", 8, max_episode_steps=200, clip_reward=True))
+    assert w.isWrapper() and w.nEnvs() == 8 and w.venv._norm["gamma"] == 0.99 and w.venv._norm["clip_obs"] == 10.0
+    assert w.actionSpace().n == 3
+
+
+def test_counter_word_layout_constants_documented():
+    """The packed counter word is part of the ABI: the header's bit widths must match what the tests decode."""
+    hdr = open(os.path.join(ROOT, "include", "gymhip.h")).read()
+    assert int(re.search(r"GYMHIP_COUNTER_STEP_BITS_CARTPOLE (\d+)", hdr).group(1)) == 10
+    assert int(re.search(r"GYMHIP_COUNTER_STEP_BITS_MOUNTAINCAR (\d+)", hdr).group(1)) == 30
+    # a CartPole episode never exceeds 501 steps (cartpole.cpp:64) < 2^10; 20 cursor bits = 1,048,575 tape rows
+    assert 501 < 1 << 10
