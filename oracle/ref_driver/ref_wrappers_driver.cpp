@@ -1,0 +1,87 @@
+// ref_wrappers_driver.cpp — OUR driver around the REFERENCE's own headers, compiled in place from /root/reference by
+// oracle/Makefile (target _ref).  Nothing of the reference is copied: the #includes below resolve to its files where
+// they lie.  Used only in the build container to pin oracle rows A4 (TimeLimit), A5 (ClipRewardEnv), A8 (Monitor) and
+// A9 (RunningMeanStd); outputs are compared with oracle/gym_oracle.cpp by tests/test_ref_pin.py and frozen as
+// tests/golden/ref_*.npz so the pin also travels to the GPU box.
+//
+// usage: ref_wrappers_driver wrappers <in> <out>   |   ref_wrappers_driver rms <in> <out>
+#include "wrappers/time_limit.h"
+#include "wrappers/clip_reward.h"
+#include "wrappers/monitor.h"
+#include "common/normalizers/running_mean_std.h"
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+// A scripted env: reward/done come from a tape; observation = steps taken.  Derives from the reference's gym::Env.
+struct ScriptEnv : gym::Env<std::vector<double>, int> {
+    std::vector<float> rew; std::vector<uint8_t> dn; size_t t = 0;
+    ScriptEnv(std::vector<float> r, std::vector<uint8_t> d) : rew(std::move(r)), dn(std::move(d)) {}
+    std::vector<double> reset() noexcept override { return {double(t)}; }
+    StepT step(const int&) noexcept override {
+        size_t i = t % rew.size(); t++;
+        return {{double(t)}, rew[i], dn[i] != 0, {}};
+    }
+};
+
+template <class T> bool rd(FILE* f, T* p, size_t n) { return fread(p, sizeof(T), n, f) == n; }
+
+int run_wrappers(const char* in, const char* out) {
+    FILE* f = fopen(in, "rb"); if (!f) return 2;
+    int64_t L, max_steps, steps, flags;
+    if (!rd(f, &L, 1) || !rd(f, &max_steps, 1) || !rd(f, &steps, 1) || !rd(f, &flags, 1)) return 2;
+    std::vector<float> rew(L); std::vector<uint8_t> dn(L);
+    if (!rd(f, rew.data(), L) || !rd(f, dn.data(), L)) return 2;
+    fclose(f);
+    using TL = gym::TimeLimit<ScriptEnv>;
+    using CR = gym::ClipRewardEnv<TL>;
+    using MO = gym::Monitor<CR, true>;
+    auto env = std::make_unique<MO>(std::make_unique<CR>(std::make_unique<TL>(std::make_unique<ScriptEnv>(rew, dn), std::optional<size_t>((size_t)max_steps))));
+    FILE* o = fopen(out, "wb"); if (!o) return 2;
+    env->reset();
+    for (int64_t s = 0; s < steps; s++) {
+        auto r = env->step(0);
+        float reward = r.reward; uint8_t done = r.done, has_tr = r.info.contains("TimeLimit.truncated"), tr = 0, has_ep = r.info.contains("episode");
+        float ep_r = 0, ep_l = 0;
+        if (has_tr) tr = std::any_cast<bool>(r.info["TimeLimit.truncated"]);
+        if (has_ep) { auto e = std::any_cast<gym::Result>(r.info["episode"]); ep_r = e.r; ep_l = e.l; }
+        fwrite(&reward, 4, 1, o); fwrite(&done, 1, 1, o); fwrite(&has_tr, 1, 1, o); fwrite(&tr, 1, 1, o); fwrite(&has_ep, 1, 1, o);
+        fwrite(&ep_r, 4, 1, o); fwrite(&ep_l, 4, 1, o);
+        if (r.done) env->reset();   // what SyncVecEnv::stepPerWorker does (sync_env.h:92-100)
+    }
+    fclose(o);
+    return 0;
+}
+
+int run_rms(const char* in, const char* out) {
+    FILE* f = fopen(in, "rb"); if (!f) return 2;
+    int64_t nb, F;
+    if (!rd(f, &nb, 1) || !rd(f, &F, 1)) return 2;
+    RunningMeanStd rms(std::vector<int64_t>{F});
+    FILE* o = fopen(out, "wb"); if (!o) return 2;
+    for (int64_t b = 0; b < nb; b++) {
+        int64_t n; if (!rd(f, &n, 1)) return 2;
+        std::vector<float> x(n * F); if (!rd(f, x.data(), n * F)) return 2;
+        auto t = torch::from_blob(x.data(), {n, F}, torch::kFloat32).clone();
+        // batch moments exactly as RunningMeanStdImpl::update computes them, also written out so the merge can be checked alone
+        auto bm = t.mean(0), bv = t.var(0, false);
+        rms->update(t);
+        auto mean = rms->mean<false>().contiguous(), var = rms->var<false>().contiguous(); float cnt = rms->count().item<float>();
+        fwrite(bm.contiguous().data_ptr<float>(), 4, F, o); fwrite(bv.contiguous().data_ptr<float>(), 4, F, o);
+        fwrite(mean.data_ptr<float>(), 4, F, o); fwrite(var.data_ptr<float>(), 4, F, o); fwrite(&cnt, 4, 1, o);
+    }
+    fclose(f); fclose(o);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc != 4) { fprintf(stderr, "usage: %s wrappers|rms <in> <out>\n", argv[0]); return 1; }
+    if (!strcmp(argv[1], "wrappers")) return run_wrappers(argv[2], argv[3]);
+    if (!strcmp(argv[1], "rms")) return run_rms(argv[2], argv[3]);
+    return 1;
+}

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Freezes outputs of the REFERENCE's own code (oracle/_ref/ref_wrappers_driver: the reference's TimeLimit /
+ClipRewardEnv / Monitor / RunningMeanStd headers compiled in place against libtorch) into tests/golden/ref_*.npz.
+
+Run in the build container after `make -C oracle _ref`.  Inputs are regenerated from the seeds stored beside the
+outputs; only data is committed, never reference source."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_wrappers_driver")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+REC = np.dtype([("reward", "<f4"), ("done", "u1"), ("has_trunc", "u1"), ("trunc", "u1"), ("has_ep", "u1"), ("ep_r", "<f4"), ("ep_l", "<f4")])
+
+
+def wrapper_script(seed, L):
+    rng = np.random.default_rng(seed)
+    rew = rng.choice(np.array([0.0, -0.0, 1.0, -1.0, 0.25, -7.5, 3.0, 1e-3], np.float32), L).astype(np.float32)
+    done = (rng.random(L) < 0.07).astype(np.uint8)
+    return rew, done
+
+
+def run_wrappers(rew, done, max_steps, steps):
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
+        with open(fin, "wb") as f:
+            f.write(np.array([rew.size, max_steps, steps, 7], np.int64).tobytes()); f.write(rew.tobytes()); f.write(done.tobytes())
+        subprocess.run([DRIVER, "wrappers", fin, fout], check=True, capture_output=True)
+        return np.fromfile(fout, REC)
+
+
+def rms_batches(seed, nb, F):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(nb):
+        n = int(rng.integers(1, 3000))
+        out.append((rng.normal(size=(n, F)) * [1, 10, 0.01, 3][:F] + [0, 5, -2, 100 * (k % 3)][:F]).astype(np.float32))
+    out.append(np.full((512, F), -0.5, np.float32))       # identical rows: batch variance exactly 0
+    out.append(np.full((1, F), 3.0, np.float32))          # single-row batch
+    return out
+
+
+def run_rms(batches, F):
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
+        with open(fin, "wb") as f:
+            f.write(np.array([len(batches), F], np.int64).tobytes())
+            for x in batches:
+                f.write(np.array([x.shape[0]], np.int64).tobytes()); f.write(np.ascontiguousarray(x).tobytes())
+        subprocess.run([DRIVER, "rms", fin, fout], check=True, capture_output=True)
+        return np.fromfile(fout, np.float32).reshape(len(batches), 4 * F + 1)
+
+
+def main():
+    rew, done = wrapper_script(11, 997)
+    rec = run_wrappers(rew, done, 13, 4000)
+    np.savez_compressed(os.path.join(OUT, "ref_wrappers.npz"), script_seed=11, script_len=997, max_steps=13, steps=4000,
+                        **{k: rec[k] for k in REC.names})
+    F = 4
+    rows = run_rms(rms_batches(5, 30, F), F)
+    np.savez_compressed(os.path.join(OUT, "ref_rms.npz"), batch_seed=5, n_batches=30, F=F, rows=rows)
+    print("reference-built golden vectors written")
+
+
+if __name__ == "__main__":
+    main()
