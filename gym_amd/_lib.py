@@ -120,6 +120,9 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise GymhipError(f"{LIB_PATH} not found: the HIP engine is not built and there is no CPU fallback")
+    # torch first: its bundled HIP runtime (SONAME libamdhip64.so.7) must already be loaded so that libgymhip's NEEDED entry
+    # resolves to that same copy — one HIP runtime per process (gym_amd/csrc/Makefile, INTEGRATION.md "link order").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported

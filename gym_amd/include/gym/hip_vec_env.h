@@ -1,0 +1,170 @@
+// hip_vec_env.h — gym::HipVecEnv : gym::VecEnv<false>, the drop-in for
+//   SyncVecEnv<Monitor<ClipRewardEnv<TimeLimit<CartPoleEnv|MountainCarEnv>>>, false>  [+ VecNormalize<false,...>]
+// (wrappers/vec_env/sync_env.h, vec_normalize.h) on one MI355X.  Header-only; all compute is behind the C ABI in
+// include/gymhip.h (libgymhip.so).  libtorch is used only to hand results back as torch::Tensor views of device memory.
+//
+// Inside the reference tree:   #define GYMHIP_USE_REFERENCE_HEADERS  +  #include "wrappers/vec_env/base.h"  first.
+// Elsewhere the stand-alone mirror in gym/vec_env.h supplies gym::VecEnv<false>.
+#pragma once
+#include <chrono>
+#include <cstdio>
+#include <functional>
+#include <string>
+
+#include "gym/vec_env.h"
+#include "gymhip.h"
+
+namespace gym {
+
+struct HipVecEnvOptions {
+    int env_kind = GYMHIP_ENV_CARTPOLE;       // GYMHIP_ENV_CARTPOLE | GYMHIP_ENV_MOUNTAINCAR
+    int64_t n_envs = 1;                       // envs on THIS GPU
+    int64_t env_offset = 0;                   // global index of local env 0 (sharding: env i is seeded seed + env_offset + i)
+    int max_episode_steps = 0;                // TimeLimit (time_limit.h:22-26); 0 = no TimeLimit wrapper
+    bool clip_reward = false;                 // ClipRewardEnv
+    bool monitor = true;                      // Monitor
+    bool lockstep = true;                     // reference-exact arithmetic (double state); false = float-state throughput mode
+    bool host_drawn_resets = true;            // std::mt19937 reset tape (reference-exact); false = stateless counter RNG
+    int64_t tape_episodes = 2048;             // reset-tape rows per env
+    bool norm_obs = false, norm_reward = false, training = true;   // VecNormalize<false, training, normReward, normObs>
+    float clip_obs = 10.f, clip_rew = 10.f, gamma = 0.99f, epsilon = 1e-8f;   // vec_normalize.h:24-27
+    int device = 0;
+    void* stream = nullptr;                   // hipStream_t; nullptr = the default stream
+    // Sharded runs with the normaliser on: sums `count` doubles at `moments` (device) over all ranks on `stream`
+    // (e.g. ncclAllReduce(moments, moments, count, ncclDouble, ncclSum, comm, stream)).  Empty = single GPU.
+    std::function<void(double* moments, size_t count, void* stream)> allreduce;
+};
+
+class HipVecEnv : public VecEnv<false> {
+public:
+    explicit HipVecEnv(HipVecEnvOptions o) : VecEnv<false>((int)o.n_envs, makeObsSpace(o.env_kind), makeActSpace(o.env_kind)), opt(std::move(o)) {
+        t_start = std::chrono::high_resolution_clock::now();
+    }
+    ~HipVecEnv() override { if (h) gymhip_destroy(h); }
+    HipVecEnv(HipVecEnv const&) = delete;
+    HipVecEnv& operator=(HipVecEnv const&) = delete;
+
+    static std::unique_ptr<VecEnv<false>> make(HipVecEnvOptions o) { return std::make_unique<HipVecEnv>(std::move(o)); }   // sync_env.h:62-64 idiom
+
+    std::vector<size_t> seed(size_t _seed) noexcept override {   // sync_env.h:74-83
+        seeded = true; seed_value = _seed;
+        std::vector<size_t> s(numEnvs);
+        for (int i = 0; i < numEnvs; i++) s[i] = _seed + (size_t)opt.env_offset + (size_t)i;
+        return s;
+    }
+
+    torch::Tensor reset() noexcept override {   // sync_env.h:66-72 / vec_normalize.h:145-157
+        if (!ensure()) return {};
+        if (!ok(gymhip_reset_begin(h, opt.stream), "gymhip_reset_begin")) return {};
+        if (hasNorm() && opt.allreduce) opt.allreduce(buf.moments, (size_t)buf.moments_len, opt.stream);
+        if (!ok(gymhip_reset_finish(h, opt.stream), "gymhip_reset_finish")) return {};
+        return opt.norm_obs ? obs_norm : obs;
+    }
+
+    void stepAsync(torch::Tensor const& actions) noexcept override {   // sync_env.h:85-87
+        // TensorAdapter::decode narrows any tensor to int32 (tensor_adapter.cpp:22-23); int32/int64/uint8 device tensors go straight in
+        pending = actions;
+    }
+
+    StepT stepWait() noexcept override {   // sync_env.h:114-123 / vec_normalize.h:159-177
+        if (!h || !pending.defined()) { std::fprintf(stderr, "HipVecEnv::stepWait before reset()/stepAsync()\n"); return {}; }
+        torch::Tensor a = pending;
+        int dt;
+        if (a.is_cuda() && a.is_contiguous() && a.scalar_type() == torch::kInt32) dt = GYMHIP_ACT_I32;
+        else if (a.is_cuda() && a.is_contiguous() && a.scalar_type() == torch::kInt64) dt = GYMHIP_ACT_I64;
+        else if (a.is_cuda() && a.is_contiguous() && a.scalar_type() == torch::kUInt8) dt = GYMHIP_ACT_U8;
+        else { a = a.to(torch::Device(torch::kCUDA, opt.device), torch::kInt32).contiguous(); dt = GYMHIP_ACT_I32; }
+        if (a.numel() != numEnvs) { std::fprintf(stderr, "HipVecEnv: expected %d actions, got %lld\n", numEnvs, (long long)a.numel()); return {}; }
+        if (!ok(gymhip_step_begin(h, a.data_ptr(), dt, opt.stream), "gymhip_step_begin")) return {};
+        if (hasNorm() && opt.allreduce) opt.allreduce(buf.moments, (size_t)buf.moments_len, opt.stream);
+        if (!ok(gymhip_step_finish(h, opt.stream), "gymhip_step_finish")) return {};
+        pending = torch::Tensor();
+        return {opt.norm_obs ? obs_norm : obs, reward.unsqueeze(-1), done.unsqueeze(-1), {}};   // sync_env.h:107-112 shapes
+    }
+
+    // info maps for the envs that just finished (monitor.h:86-97, time_limit.h:32), built on demand: N unordered_maps per
+    // step are the reference's host bottleneck.  Entry i is empty unless done[i] != 0.  Synchronises the stream.
+    std::vector<AnyMap> infos() {
+        std::vector<AnyMap> out(numEnvs);
+        auto o = torch::TensorOptions().device(torch::kCUDA, opt.device);
+        auto len = torch::empty({numEnvs}, o.dtype(torch::kInt32)), tr = torch::empty({numEnvs}, o.dtype(torch::kUInt8)), ret = torch::empty({numEnvs}, o.dtype(torch::kFloat32));
+        if (!ok(gymhip_decode_counters(h, nullptr, len.data_ptr<int32_t>(), tr.data_ptr<uint8_t>(), ret.data_ptr<float>(), nullptr, opt.stream), "gymhip_decode_counters")) return out;
+        auto hl = len.cpu(), ht = tr.cpu(), hr = ret.cpu(), hd = done.cpu();
+        float t = std::chrono::duration<float>(std::chrono::high_resolution_clock::now() - t_start).count();
+        for (int i = 0; i < numEnvs; i++) {
+            if (hd.data_ptr<float>()[i] == 0.f) continue;
+            if (opt.max_episode_steps > 0) out[i]["TimeLimit.truncated"] = bool(ht.data_ptr<uint8_t>()[i]);
+            if (opt.monitor) out[i]["episode"] = Result{hr.data_ptr<float>()[i], float(hl.data_ptr<int32_t>()[i]), t};
+        }
+        return out;
+    }
+
+    torch::Tensor oldObs() const { return obs; }                         // vec_normalize.h:94
+    torch::Tensor normStats() const { return norm_stats; }               // [2F+4]: obs mean, var, count, ret mean, var, count
+    gymhip_engine* handle() const { return h; }
+
+    torch::Tensor reset(int) override { throw std::runtime_error("HipVecEnv::reset(int index): not implemented (per-index paths)"); }
+    StepT step(int, torch::Tensor const&) noexcept override { return {}; }   // the reference's own stub returns buffered values (sync_env.h:141-157)
+    void render() const override {}
+
+private:
+    static std::shared_ptr<Space> makeObsSpace(int kind) {
+        if (kind == GYMHIP_ENV_CARTPOLE) {   // cartpole.cpp:10-16
+            const float fm = std::numeric_limits<float>::max(), x2 = 2.4f * 2, th2 = float(12 * 2 * M_PI / 360) * 2;
+            return std::make_shared<Box<float>>(std::vector<Range<float>>{{-x2, x2}, {-fm, fm}, {-th2, th2}, {-fm, fm}}, Shape{{4}, c10::kFloat});
+        }
+        return std::make_shared<Box<float>>(Shape{{2}, c10::kFloat});   // mountain_car.cpp:11
+    }
+    static std::shared_ptr<Space> makeActSpace(int kind) { return std::make_shared<Discrete>(kind == GYMHIP_ENV_CARTPOLE ? 2 : 3); }
+
+    bool hasNorm() const { return opt.norm_obs || opt.norm_reward; }
+    bool ok(int rc, const char* what) const noexcept {
+        if (rc != GYMHIP_OK) std::fprintf(stderr, "HipVecEnv: %s failed (%d): %s\n", what, rc, gymhip_last_error());   // reference style: stderr, no throw (cartpole.cpp:77-82)
+        return rc == GYMHIP_OK;
+    }
+    template <typename T> torch::Tensor view(T* p, std::vector<int64_t> shape, c10::ScalarType dt) const {
+        if (!p) return {};
+        return torch::from_blob((void*)p, shape, torch::TensorOptions().dtype(dt).device(torch::kCUDA, opt.device));
+    }
+    bool ensure() noexcept {
+        if (h) return true;
+        gymhip_config c{};
+        c.struct_size = sizeof c;
+        c.env_kind = opt.env_kind;
+        c.precision = opt.lockstep ? GYMHIP_PRECISION_LOCKSTEP_F64 : GYMHIP_PRECISION_F32;
+        const bool tape = opt.host_drawn_resets && opt.env_kind == GYMHIP_ENV_CARTPOLE;
+        c.reset_mode = tape ? GYMHIP_RESET_TAPE : GYMHIP_RESET_COUNTER_RNG;
+        c.wrappers = (opt.max_episode_steps > 0 ? GYMHIP_WRAP_TIME_LIMIT : 0u) | (opt.clip_reward ? GYMHIP_WRAP_CLIP_REWARD : 0u) |
+                     (opt.monitor ? GYMHIP_WRAP_MONITOR : 0u) | (opt.norm_obs ? GYMHIP_WRAP_NORM_OBS : 0u) |
+                     (opt.norm_reward ? GYMHIP_WRAP_NORM_REWARD : 0u) | (opt.training ? GYMHIP_WRAP_NORM_TRAINING : 0u);
+        c.max_episode_steps = opt.max_episode_steps;
+        c.n_envs = opt.n_envs; c.env_offset = opt.env_offset; c.seed = seeded ? seed_value : 0;
+        c.clip_obs = opt.clip_obs; c.clip_reward = opt.clip_rew; c.gamma = opt.gamma; c.epsilon = opt.epsilon;
+        if (!ok(gymhip_create(&c, opt.device, nullptr, 0, &h), "gymhip_create")) { h = nullptr; return false; }
+        if (tape && !ok(seeded ? gymhip_seed_reset_tape(h, seed_value, opt.tape_episodes) : gymhip_unseeded_reset_tape(h, opt.tape_episodes), "reset tape")) return false;
+        if (!ok(gymhip_get_buffers(h, &buf), "gymhip_get_buffers")) return false;
+        const int64_t n = opt.n_envs, F = buf.obs_dim;
+        obs = view(buf.obs, {n, F}, c10::kFloat);
+        obs_norm = view(buf.obs_norm, {n, F}, c10::kFloat);
+        reward = view(buf.reward, {n}, c10::kFloat);
+        done = view(buf.done, {n}, c10::kFloat);
+        norm_stats = view(buf.norm_stats, {2 * F + 4}, c10::kFloat);
+        return true;
+    }
+
+    HipVecEnvOptions opt;
+    gymhip_engine* h = nullptr;
+    gymhip_buffers buf{};
+    torch::Tensor obs, obs_norm, reward, done, norm_stats, pending;
+    bool seeded = false;
+    size_t seed_value = 0;
+    std::chrono::high_resolution_clock::time_point t_start;
+};
+
+// gym_.h:15-16 — TrainingVecNormRO<false> = VecNormalize<false, true, true, true> over a sync vec env
+inline std::unique_ptr<VecEnv<false>> makeTrainingVecNormRO(HipVecEnvOptions o) {
+    o.norm_obs = o.norm_reward = o.training = true;
+    return HipVecEnv::make(std::move(o));
+}
+
+}  // namespace gym

@@ -1,0 +1,48 @@
+// A training-loop-shaped driver of gym::HipVecEnv, modelled on the reference's own smoke test
+// (test/classic_control.cpp:69-99, p_test_run): build the vec env, reset, check shapes, step with a tensor of actions.
+// Prints one line per step so tests/test_cpp_host.py can compare against the CPU oracle.
+//   usage: hip_vec_env_demo <cartpole|mountaincar> <n_envs> <steps> <norm 0|1>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "gym/hip_vec_env.h"
+
+int main(int argc, char** argv) {
+    if (argc != 5) { std::fprintf(stderr, "usage: %s cartpole|mountaincar n_envs steps norm\n", argv[0]); return 2; }
+    const bool cart = !std::strcmp(argv[1], "cartpole");
+    const int64_t n = std::atoll(argv[2]);
+    const int steps = std::atoi(argv[3]);
+    const bool norm = std::atoi(argv[4]) != 0;
+
+    std::setvbuf(stdout, nullptr, _IOLBF, 0);
+    gym::HipVecEnvOptions o;
+    o.env_kind = cart ? GYMHIP_ENV_CARTPOLE : GYMHIP_ENV_MOUNTAINCAR;
+    o.n_envs = n;
+    o.max_episode_steps = cart ? 500 : 200;
+    o.clip_reward = !cart;
+    o.tape_episodes = steps / 8 + 4;
+    std::unique_ptr<gym::VecEnv<false>> env = norm ? gym::makeTrainingVecNormRO(o) : gym::HipVecEnv::make(o);
+    auto seeds = env->seed(7);
+    if ((int64_t)seeds.size() != n || seeds[1] != 8) return 3;
+    const int64_t n_act = env->actionSpace()->as<gym::Discrete>()->n;
+
+    auto obs = env->reset();
+    if (obs.size(0) != n || obs.size(1) != (cart ? 4 : 2) || obs.scalar_type() != torch::kFloat32) return 4;   // test/classic_control.cpp:85-86
+    std::printf("reset %.9e\n", obs.to(torch::kFloat64).sum().item<double>());
+    auto idx = torch::arange(n, torch::TensorOptions().dtype(torch::kInt64).device(torch::kCUDA, 0));
+    for (int t = 0; t < steps; t++) {
+        auto actions = (idx * 7 + t * 3) % n_act;                       // int64 device tensor, like torch::randint(n, N_env)
+        auto r = env->step(actions);
+        if (!r.reward.defined() || r.reward.size(0) != n || r.reward.size(1) != 1 || r.done.size(1) != 1) return 5;   // sync_env.h:107-112
+        std::printf("step %d %lld %.9e %.9e\n", t, (long long)r.done.sum().item<float>(), r.observation.to(torch::kFloat64).sum().item<double>(),
+                    r.reward.to(torch::kFloat64).sum().item<double>());
+        if (t == steps - 1) {
+            auto infos = static_cast<gym::HipVecEnv*>(env.get())->infos();
+            int with_ep = 0; double len_sum = 0;
+            for (auto& m : infos) if (m.count("episode")) { with_ep++; len_sum += std::any_cast<gym::Result>(m["episode"]).l; }
+            std::printf("infos %d %.1f\n", with_ep, len_sum);
+        }
+    }
+    return 0;
+}

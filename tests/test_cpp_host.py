@@ -1,0 +1,51 @@
+"""The C++ host mirror (gym_amd/include/gym/hip_vec_env.h): builds against libtorch on CPU; on the GPU a driver shaped
+like the reference's own smoke test (test/classic_control.cpp:69-99) must reproduce the oracle's streams."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.oracle_lib import CARTPOLE, MOUNTAINCAR, F_CLIP_REWARD, F_MONITOR, F_TIME_LIMIT
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "bin", "hip_vec_env_demo")
+
+
+def test_cpp_mirror_compiles_and_links():
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.exists(BIN)
+
+
+def _run(env, n, steps, norm):
+    r = subprocess.run([BIN, env, str(n), str(steps), str(int(norm))], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    return [l.split() for l in r.stdout.strip().splitlines()]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,norm", [("cartpole", False), ("mountaincar", True)])
+def test_cpp_training_loop_matches_oracle(oracle, env, norm):
+    assert os.path.exists(BIN), "build tests/cpp first (python -c 'import __graft_entry__ as g; g.build()')"
+    n, steps = 2048, 260
+    cart = env == "cartpole"
+    n_act = 2 if cart else 3
+    v = oracle.vec(CARTPOLE if cart else MOUNTAINCAR, n, F_TIME_LIMIT | F_MONITOR | (0 if cart else F_CLIP_REWARD), 500 if cart else 200)
+    v.seed(7)
+    if norm:
+        v.attach_norm()
+    lines = _run(env, n, steps, norm)
+    obs0 = v.norm_reset()[0] if norm else v.reset()
+    assert lines[0][0] == "reset" and np.isclose(float(lines[0][1]), obs0.astype(np.float64).sum(), rtol=1e-6, atol=1e-3)
+    idx = np.arange(n, dtype=np.int64)
+    for t in range(steps):
+        a = ((idx * 7 + t * 3) % n_act).astype(np.int32)
+        r = v.norm_step(a) if norm else v.step(a)
+        tag, tt, dones, obs_sum, rew_sum = lines[1 + t]
+        assert tag == "step" and int(tt) == t
+        assert int(dones) == int(r["done"].sum()), t
+        assert np.isclose(float(obs_sum), r["obs"].astype(np.float64).sum(), rtol=1e-5, atol=2e-2 if norm else 1e-3), t
+        assert np.isclose(float(rew_sum), r["reward"].astype(np.float64).sum(), rtol=1e-5, atol=1e-3), t
+    d = r["done"] != 0
+    assert lines[-1][0] == "infos" and int(lines[-1][1]) == int(d.sum()) and float(lines[-1][2]) == float(r["ep_l"][d].sum())
