@@ -106,8 +106,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # Rehearsal knobs for a 1-GPU box only (the real N>1 run is one rank per GPU over RCCL): all ranks on device 0, gloo.
+        if os.environ.get("GYM_BENCH_SINGLE_DEVICE") == "1":
+            local_rank = 0
+        backend = os.environ.get("GYM_BENCH_BACKEND", "nccl")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
         local_rank = 0
