@@ -32,6 +32,13 @@ BYTES_PER_STEP = {
 }
 
 
+def max_over_ranks(torch, dist, dt):
+    """MAX of a host scalar over ranks (device tensor for nccl, host tensor otherwise)."""
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def time_engine(torch, dist, eng, actions, steps, warmup, world):
     """W untimed + K timed VecEnv steps.  Returns (wall seconds max over ranks, mean kernel ms from HIP events)."""
     for w in range(warmup):
@@ -52,9 +59,7 @@ def time_engine(torch, dist, eng, actions, steps, warmup, world):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = max_over_ranks(torch, dist, dt)
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
     return dt, kern_ms
 
@@ -93,12 +98,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (f32 / MountainCar) measurements")
     args = ap.parse_args()
+    if os.environ.get("GYM_BENCH_TRACE"):   # debugging aid: dump every thread's stack and exit if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["GYM_BENCH_TRACE"]), exit=True)
 
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
     from gym_amd import _lib as L
     from gym_amd.engine import Engine, EngineConfig
+    from gym_amd.vec_env import allreduce_sum
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -162,13 +171,13 @@ def main():
         def do_reset():
             eng.reset_begin()
             if world > 1:
-                dist.all_reduce(eng.moments)
+                allreduce_sum(eng.moments)
             eng.reset_finish()
 
         def do_step(a):
             eng.step_begin(a)
             if world > 1:
-                dist.all_reduce(eng.moments)
+                allreduce_sum(eng.moments)
             eng.step_finish()
 
         do_reset()
@@ -188,9 +197,7 @@ def main():
             dist.barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            dt = max_over_ranks(torch, dist, dt)
         stats = eng.get_norm_stats()
         eng.close()
         bps = 16 + 16 + 8 + 4 + 8 + 8 + 4 + 4 + (8 + 8 + 4 + 4)   # step kernel 68 B + normalise kernel 24 B
@@ -230,36 +237,30 @@ def main():
                 "materialize_GBs": round((4 * 7056 + 4 * 4 * 7056) * n4 / (ms_mat * 1e-3) / 1e9, 1)}
 
     main_m = measure(args.env, args.mode)
-    extra = {}
-    if not args.no_extra and args.env == "cartpole" and args.mode == "lockstep":
-        for env, mode in (("cartpole", "f32"), ("mountaincar", "lockstep"), ("mountaincar", "f32")):
-            m = measure(env, mode)
-            extra[f"{env}_{mode}"] = {"value": m["value"], "unit": "env-steps/s", "kernel_ms": round(m["kernel_ms"], 4),
-                                      "bytes_per_env_step": m["bytes_per_env_step"], "achieved_GBs": round(m["achieved_gbs"], 1),
-                                      "frac": round(m["achieved_gbs"] / HBM_PEAK_GBS, 4)}
-        extra["config3_mountaincar_vecnormalize_1M_per_gpu"] = measure_config3(1 << 20, args.steps)
-        extra["config3_mountaincar_vecnormalize_16M_per_gpu"] = measure_config3(1 << 24, max(20, args.steps // 4))
-        if rank == 0:
-            extra["config4_atari_preprocess_4096"] = measure_atari(4096, max(20, args.steps // 4))
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        c = cpu_baseline(16384, args.cpu_seconds)
-        v, thr, nsteps, secs = c["all"]
-        cpu = {"value": v, "unit": "env-steps/s", "cores": thr, "kind": "port",
-               "sample": f"CartPole+TimeLimit(500)+Monitor, 16384 envs, {nsteps} env-steps in {secs:.1f}s, OpenMP over envs "
-                         f"(ASyncVecEnv shape); same loop on 1 core: {c['1'][0]:.3e} env-steps/s; os.cpu_count()={os.cpu_count()}"}
-
+    # PMC-measured HBM bytes per launch of the headline kernel (profiles/traffic.json; valid for the profiled launch size only)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(f"{args.env}_{args.mode}", {}).get("hbm_bytes_per_launch")
+            rec = json.load(open(tpath)).get(f"{args.env}_{args.mode}", {})
+            if rec.get("envs_per_launch") == n and args.reset_mode == "tape":
+                traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
-    if rank == 0:
-        line = {
+    extra, cpu = {}, None
+    printed = [False]
+
+    def emit():
+        if rank != 0 or printed[0]:
+            return
+        printed[0] = True
+        line = make_line()
+        print(json.dumps(line), flush=True)
+
+    def make_line():
+        return {
             "metric": "env-steps/sec (whole node), CartPole vec_env", "value": main_m["value"], "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_m["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.mode == "lockstep" else "f32",
@@ -275,9 +276,58 @@ def main():
             "cpu_baseline": cpu,
             "extra": extra,
         }
-        print(json.dumps(line), flush=True)
+
+    # The headline is measured; everything below is secondary.  A watchdog on every rank guarantees that the ONE JSON line
+    # still comes out (and the job ends) if a secondary measurement stalls, e.g. a rank that failed before a collective.
+    import threading
+
+    def on_stall():
+        extra["error"] = "secondary measurements exceeded the time limit; headline unaffected"
+        emit()
+        os._exit(0)
+
+    dog = threading.Timer(float(os.environ.get("GYM_BENCH_EXTRA_TIMEOUT", "300")), on_stall)
+    dog.daemon = True
+    dog.start()
+
+    def guarded(key, fn, *a):
+        try:
+            extra[key] = fn(*a)
+        except Exception as e:  # noqa: BLE001 — report, never lose the headline line
+            extra[key] = {"error": f"{type(e).__name__}: {e}"}
+
+    def classic(env, mode):
+        m = measure(env, mode)
+        return {"value": m["value"], "unit": "env-steps/s", "kernel_ms": round(m["kernel_ms"], 4),
+                "bytes_per_env_step": m["bytes_per_env_step"], "achieved_GBs": round(m["achieved_gbs"], 1),
+                "frac": round(m["achieved_gbs"] / HBM_PEAK_GBS, 4)}
+
+    if not args.no_extra and args.env == "cartpole" and args.mode == "lockstep":
+        for env, mode in (("cartpole", "f32"), ("mountaincar", "lockstep"), ("mountaincar", "f32")):
+            guarded(f"{env}_{mode}", classic, env, mode)
+        guarded("config3_mountaincar_vecnormalize_1M_per_gpu", measure_config3, 1 << 20, args.steps)
+        guarded("config3_mountaincar_vecnormalize_16M_per_gpu", measure_config3, 1 << 24, max(20, args.steps // 4))
+        if rank == 0:
+            guarded("config4_atari_preprocess_4096", measure_atari, 4096, max(20, args.steps // 4))
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            c = cpu_baseline(16384, args.cpu_seconds)
+            v, thr, nsteps, secs = c["all"]
+            cpu = {"value": v, "unit": "env-steps/s", "cores": thr, "kind": "port",
+                   "sample": f"CartPole+TimeLimit(500)+Monitor, 16384 envs, {nsteps} env-steps in {secs:.1f}s, OpenMP over envs "
+                             f"(ASyncVecEnv shape); same loop on 1 core: {c['1'][0]:.3e} env-steps/s; os.cpu_count()={os.cpu_count()}"}
+        except Exception as e:  # noqa: BLE001
+            cpu = {"error": f"{type(e).__name__}: {e}"}
+
+    dog.cancel()
+    emit()
     if world > 1:
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 if __name__ == "__main__":

@@ -114,6 +114,20 @@ class VecEnv:
         return []
 
 
+def allreduce_sum(t: torch.Tensor, group=None):
+    """SUM all-reduce of a small device tensor in place.  Backend nccl (= RCCL over xGMI): directly on the device tensor,
+    ordered on the current stream.  Any other backend (gloo: CPU tests and 1-GPU rehearsals) is staged through the host —
+    gloo's own CUDA path deadlocked on repeated calls on the MI355X box."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(t, group=group)
+    else:
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    return t
+
+
 def shard_range(n_global: int, rank: int, world: int):
     """GPU g of G owns the contiguous env range [g*N/G, (g+1)*N/G); seeds follow the GLOBAL index."""
     lo = (n_global * rank) // world
@@ -186,8 +200,7 @@ class HipVecEnv(VecEnv):
 
     def _allreduce_moments(self):
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.engine.moments, group=self.group)   # RCCL: 2F+6 doubles, latency-bound
+            allreduce_sum(self.engine.moments, self.group)   # RCCL: 2F+6 doubles, latency-bound
 
     # -- VecEnv interface ------------------------------------------------------------------------------------------
     def seed(self, _seed: int):
@@ -230,8 +243,7 @@ class HipVecEnv(VecEnv):
         """(episodes, sum of returns, sum of lengths) over ALL shards — Monitor getters in aggregate (monitor.h:104-107)."""
         tot = torch.from_numpy(self.engine.episode_stats()).to(self.engine.device)
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(tot, group=self.group)
+            allreduce_sum(tot, self.group)
         return tot.cpu().numpy()
 
 
