@@ -23,12 +23,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
-# Algorithmic HBM bytes per env-step: state read+write, obs write, action, reward, done, step counter r/w
+# Algorithmic HBM bytes per env-step (52 B, "lockstep doubles the 32 B state term"):
+# state read+write (obs rows alias the state; lockstep adds the 4 B/element residual rows), action, reward, done,
+# step counter r/w
 BYTES_PER_STEP = {
-    ("cartpole", "lockstep"): 32 + 32 + 16 + 4 + 4 + 4 + 8,   # 100
-    ("cartpole", "f32"): 16 + 16 + 4 + 4 + 4 + 8,             # 52 (obs aliases the state)
-    ("mountaincar", "lockstep"): 16 + 16 + 8 + 4 + 4 + 4 + 8,  # 60
-    ("mountaincar", "f32"): 8 + 8 + 4 + 4 + 4 + 8,             # 36
+    ("cartpole", "lockstep"): 32 + 32 + 4 + 4 + 4 + 8,        # 84
+    ("cartpole", "f32"): 16 + 16 + 4 + 4 + 4 + 8,             # 52
+    ("mountaincar", "lockstep"): 16 + 16 + 4 + 4 + 4 + 8,     # 52
+    ("mountaincar", "f32"): 8 + 8 + 4 + 4 + 4 + 8,            # 36
 }
 
 
@@ -200,7 +202,7 @@ def main():
             dt = max_over_ranks(torch, dist, dt)
         stats = eng.get_norm_stats()
         eng.close()
-        bps = 16 + 16 + 8 + 4 + 8 + 8 + 4 + 4 + (8 + 8 + 4 + 4)   # step kernel 68 B + normalise kernel 24 B
+        bps = 16 + 16 + 4 + 8 + 8 + 4 + 4 + (8 + 8 + 4 + 4)   # step kernel 60 B + normalise kernel 24 B
         return {"value": world * n3 * steps / dt, "unit": "env-steps/s", "envs_per_gpu": n3, "ms_per_step": round(dt / steps * 1e3, 4),
                 "bytes_per_env_step": bps, "achieved_GBs": round(bps * n3 * steps / dt / 1e9, 1), "collective": "all_reduce(12 x f64)/step" if world > 1 else None,
                 "obs_count": float(stats[4])}

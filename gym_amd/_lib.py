@@ -95,6 +95,7 @@ SIGNATURES = {
     "gymhip_reset_finish": (C.c_int, [_vp, _vp]),
     "gymhip_rollout": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gymhip_decode_counters": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gymhip_read_state_f64": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_episode_stats": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_poll_error": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_get_norm_stats": (C.c_int, [_vp, _vp, _vp]),

@@ -92,20 +92,42 @@ struct CartPoleC {  // cartpole.h:30-39 — float constants
     static constexpr float x_thr = 2.4f;
 };
 
+// GYMHIP_DIAG (tools/sweep_variants.sh only; never defined in the shipped library — results are WRONG when it is set):
+//   1 = trivial dynamics, no env ever done: the pure cost of the kernel's HBM streams
+//   2 = sin/cos replaced by two-term polynomials      3 = float divides replaced by reciprocal multiplies
+#ifndef GYMHIP_DIAG
+#define GYMHIP_DIAG 0
+#endif
+__device__ inline float diag_div(float a, float b) {
+#if GYMHIP_DIAG == 3
+    return a * __builtin_amdgcn_rcpf(b);
+#else
+    return a / b;
+#endif
+}
+
 // cartpole.cpp:33-68, exact precisions (A1).  Returns the env's own `done`.
 __device__ inline bool cartpole_step(double (&s)[4], int action, int time_step) {
     using C = CartPoleC;
     double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
+#if GYMHIP_DIAG == 1
+    s[0] = x + 1e-9; s[1] = x_dot + 1e-9; s[2] = theta + 1e-9 * action; s[3] = theta_dot + 1e-9;
+    return time_step < 0;
+#endif
     float force = (action == 1) ? C::force_mag : -C::force_mag;
     double sd, cd;
+#if GYMHIP_DIAG == 2
+    sd = theta - theta * theta * theta * (1.0 / 6.0); cd = 1.0 - theta * theta * 0.5;
+#else
     sincos(theta, &sd, &cd);
+#endif
     float cos_t = (float)cd, sin_t = (float)sd;
-    float temp = (float)((double)force + ((double)C::polemass_length * (theta_dot * theta_dot)) * (double)sin_t) / C::total_mass;
+    float temp = diag_div((float)((double)force + ((double)C::polemass_length * (theta_dot * theta_dot)) * (double)sin_t), C::total_mass);
     float num = C::gravity * sin_t - cos_t * temp;
-    float inner = C::masspole * (cos_t * cos_t) / C::total_mass;
+    float inner = diag_div(C::masspole * (cos_t * cos_t), C::total_mass);
     float den = (float)((double)C::length * (4.0 / 3.0 - (double)inner));
-    float theta_acc = num / den;
-    float x_acc = temp - C::polemass_length * theta_acc * cos_t / C::total_mass;
+    float theta_acc = diag_div(num, den);
+    float x_acc = temp - diag_div(C::polemass_length * theta_acc * cos_t, C::total_mass);
     x = x + (double)C::tau * x_dot;
     x_dot = x_dot + (double)(C::tau * x_acc);
     theta = theta + (double)C::tau * theta_dot;
@@ -118,15 +140,23 @@ __device__ inline bool cartpole_step(double (&s)[4], int action, int time_step) 
 __device__ inline bool cartpole_step(float (&s)[4], int action, int time_step) {
     using C = CartPoleC;
     float x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
+#if GYMHIP_DIAG == 1
+    s[0] = x + 1e-6f; s[1] = x_dot + 1e-6f; s[2] = theta + 1e-6f * action; s[3] = theta_dot + 1e-6f;
+    return time_step < 0;
+#endif
     float force = (action == 1) ? C::force_mag : -C::force_mag;
     float sin_t, cos_t;
+#if GYMHIP_DIAG == 2
+    sin_t = theta - theta * theta * theta * (1.f / 6.f); cos_t = 1.f - theta * theta * 0.5f;
+#else
     sincosf(theta, &sin_t, &cos_t);
-    float temp = (force + C::polemass_length * (theta_dot * theta_dot) * sin_t) / C::total_mass;
+#endif
+    float temp = diag_div(force + C::polemass_length * (theta_dot * theta_dot) * sin_t, C::total_mass);
     float num = C::gravity * sin_t - cos_t * temp;
-    float inner = C::masspole * (cos_t * cos_t) / C::total_mass;
+    float inner = diag_div(C::masspole * (cos_t * cos_t), C::total_mass);
     float den = C::length * (1.33333337f - inner);
-    float theta_acc = num / den;
-    float x_acc = temp - C::polemass_length * theta_acc * cos_t / C::total_mass;
+    float theta_acc = diag_div(num, den);
+    float x_acc = temp - diag_div(C::polemass_length * theta_acc * cos_t, C::total_mass);
     x = x + C::tau * x_dot;
     x_dot = x_dot + C::tau * x_acc;
     theta = theta + C::tau * theta_dot;
@@ -188,8 +218,8 @@ template <> struct EnvTraits<KIND_CARTPOLE> { static constexpr int F = 4; static
 template <> struct EnvTraits<KIND_MOUNTAINCAR> { static constexpr int F = 2; static constexpr float step_reward = -1.0f; };
 
 // ------------------------------------------------------------------------------------------------------------
-// State I/O.  LOCKSTEP: double2 planes [F/2][N] (each plane a fully coalesced 16 B/lane stream) + f32 obs rows.
-// F32: the f32 obs rows [N][F] ARE the state (float4 / float2 per lane).
+// State I/O.  F32: the f32 obs rows [N][F] ARE the state (float4 / float2 per lane).  LOCKSTEP: the same obs rows plus
+// int32 residual rows [N][F] that complete each float to the exact double (split-double, below).
 // ------------------------------------------------------------------------------------------------------------
 // Compile-time tuning knobs (profiles/ and DESIGN.md §5 record what each is worth on MI355X):
 //   GYMHIP_ILP  envs per thread per grid-stride iteration, all loads issued before the first dependent use
@@ -202,7 +232,8 @@ template <> struct EnvTraits<KIND_MOUNTAINCAR> { static constexpr int F = 2; sta
 #endif
 using f32x4 = float __attribute__((ext_vector_type(4)));
 using f32x2 = float __attribute__((ext_vector_type(2)));
-using f64x2 = double __attribute__((ext_vector_type(2)));
+using i32x4 = int32_t __attribute__((ext_vector_type(4)));
+using i32x2 = int32_t __attribute__((ext_vector_type(2)));
 template <typename V> __device__ inline V ld_stream(const V* ptr) {
 #if GYMHIP_NT
     return __builtin_nontemporal_load(ptr);
@@ -218,20 +249,54 @@ template <typename V> __device__ inline void st_stream(V* ptr, V v) {
 #endif
 }
 
-template <int F> __device__ inline void load_state(const StepBuffers& b, int64_t n, int64_t i, double (&s)[F]) {
-    const f64x2* pl = (const f64x2*)b.state;
-#pragma unroll
-    for (int k = 0; k < F / 2; k++) { f64x2 v = ld_stream(pl + (int64_t)k * n + i); s[2 * k] = v.x; s[2 * k + 1] = v.y; }
-}
-template <int F> __device__ inline void store_state(const StepBuffers& b, int64_t n, int64_t i, const double (&s)[F]) {
-    f64x2* pl = (f64x2*)b.state;
-#pragma unroll
-    for (int k = 0; k < F / 2; k++) { f64x2 v = {s[2 * k], s[2 * k + 1]}; st_stream(pl + (int64_t)k * n + i, v); }
-}
 __device__ inline void load_obs(const float* obs, int64_t i, float (&s)[4]) { f32x4 v = ld_stream((const f32x4*)obs + i); s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w; }
 __device__ inline void load_obs(const float* obs, int64_t i, float (&s)[2]) { f32x2 v = ld_stream((const f32x2*)obs + i); s[0] = v.x; s[1] = v.y; }
 __device__ inline void store_obs(float* obs, int64_t i, const float (&s)[4]) { f32x4 v = {s[0], s[1], s[2], s[3]}; st_stream((f32x4*)obs + i, v); }
 __device__ inline void store_obs(float* obs, int64_t i, const float (&s)[2]) { f32x2 v = {s[0], s[1]}; st_stream((f32x2*)obs + i, v); }
+__device__ inline void load_i32(const int32_t* a, int64_t i, int32_t (&k)[4]) { i32x4 v = ld_stream((const i32x4*)a + i); k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w; }
+__device__ inline void load_i32(const int32_t* a, int64_t i, int32_t (&k)[2]) { i32x2 v = ld_stream((const i32x2*)a + i); k[0] = v.x; k[1] = v.y; }
+__device__ inline void store_i32(int32_t* a, int64_t i, const int32_t (&k)[4]) { i32x4 v = {k[0], k[1], k[2], k[3]}; st_stream((i32x4*)a + i, v); }
+__device__ inline void store_i32(int32_t* a, int64_t i, const int32_t (&k)[2]) { i32x2 v = {k[0], k[1]}; st_stream((i32x2*)a + i, v); }
+
+// Split-double state (LOCKSTEP).  A double d is kept as the pair (f, k): f = (float)d — exactly the observation the API
+// returns, so the obs row doubles as the high half of the state — and k = (d - (double)f) * 2^(53 - e_f), e_f = f's
+// unbiased exponent.  d - f is exact (|d - f| <= ulp_f/2 = 2^(e_f-24)) and a multiple of 2^(e_f-53) (d has 53 significant
+// bits and exponent e_f or e_f - 1), so k is an integer with |k| <= 2^29, and d == (double)f + k * 2^(e_f-53) exactly.
+// 8 B per state element become 4 B beyond the obs row that is written anyway.  Not representable: nonzero |d| < 2^-126
+// and non-finite d; the dynamics cannot produce either (every value is a short sum of terms >= 2^-80 in magnitude),
+// and bit 2 of the error flag reports it if it ever happens.
+__device__ inline int32_t split_residual(double d, float f, int32_t* error_flag) {
+    const int e = (int)((__float_as_uint(f) >> 23) & 0xffu);
+    if (e == 0 || e == 255) {
+        if (d != 0.0) atomicOr(error_flag, 4);
+        return 0;
+    }
+    const double scale = __longlong_as_double((long long)(1023 + 180 - e) << 52);   // 2^(53 - (e - 127))
+    return (int32_t)((d - (double)f) * scale);
+}
+__device__ inline double split_join(float f, int32_t k) {
+    const int e = (int)((__float_as_uint(f) >> 23) & 0xffu);
+    if (e == 0 || e == 255) return (double)f;
+    const double inv = __longlong_as_double((long long)(1023 - 180 + e) << 52);     // 2^((e - 127) - 53)
+    return (double)f + (double)k * inv;
+}
+template <int F> __device__ inline void join_state(const float (&o)[F], const int32_t (&k)[F], double (&s)[F]) {
+#pragma unroll
+    for (int f = 0; f < F; f++) s[f] = split_join(o[f], k[f]);
+}
+template <int F> __device__ inline void load_state(const StepBuffers& b, int64_t i, double (&s)[F]) {
+    float o[F]; int32_t k[F];
+    load_obs(b.obs, i, o);
+    load_i32((const int32_t*)b.state, i, k);
+    join_state<F>(o, k, s);
+}
+// Stores the residual half; the caller stores o (= the float-rounded state) through store_obs.
+template <int F> __device__ inline void store_state(const StepBuffers& b, int64_t i, const double (&s)[F], const float (&o)[F], int32_t* error_flag) {
+    int32_t k[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) k[f] = split_residual(s[f], o[f], error_flag);
+    store_i32((int32_t*)b.state, i, k);
+}
 
 // Reset state of env i for episode `ep` (already range-checked).
 template <int KIND, typename T>
@@ -305,7 +370,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
     constexpr int U = GYMHIP_ILP;
     for (int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x; base < p.n; base += (int64_t)gridDim.x * (kBlock * U)) {
         // phase 1: every load of the U envs this thread owns is issued before the first dependent instruction
-        T sv[U][F];
+        float ov[U][F];
+        int32_t kv[U][LOCKSTEP ? F : 1];
         int action_v[U];
         uint32_t w_v[U];
         float ret_v[U];
@@ -313,7 +379,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
         for (int u = 0; u < U; u++) {
             const int64_t i = base + (int64_t)u * kBlock;
             if (i < p.n) {
-                if constexpr (LOCKSTEP) load_state<F>(b, p.n, i, sv[u]); else load_obs(b.obs, i, sv[u]);
+                load_obs(b.obs, i, ov[u]);
+                if constexpr (LOCKSTEP) load_i32((const int32_t*)b.state, i, kv[u]);
                 action_v[u] = (int)ld_stream(actions + i);
                 w_v[u] = ld_stream(b.counter + i);   // packed step counter / episode record / tape cursor (gymhip.h)
                 if constexpr (NORM) ret_v[u] = ret_lane ? ld_stream(b.returns + i) : 0.f;
@@ -324,7 +391,13 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
         for (int u = 0; u < U; u++) {
             const int64_t i = base + (int64_t)u * kBlock;
             if (i >= p.n) continue;
-            T (&s)[F] = sv[u];
+            T s[F];
+            if constexpr (LOCKSTEP) {
+                join_state<F>(ov[u], kv[u], s);
+            } else {
+#pragma unroll
+                for (int f = 0; f < F; f++) s[f] = ov[u][f];
+            }
             const int action = action_v[u];
             const uint32_t w = w_v[u];
             int t = CounterWord<KIND>::steps_now(w);
@@ -358,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
             float o[F];
 #pragma unroll
             for (int f = 0; f < F; f++) o[f] = (float)s[f];
-            if constexpr (LOCKSTEP) store_state<F>(b, p.n, i, s);
+            if constexpr (LOCKSTEP) store_state<F>(b, i, s, o, p.error_flag);
             store_obs(b.obs, i, o);
             st_stream(b.counter + i, CounterWord<KIND>::pack(t, cursor, done, trunc));
             st_stream(b.reward + i, reward);
@@ -409,7 +482,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepParams p) {
         float o[F];
 #pragma unroll
         for (int f = 0; f < F; f++) o[f] = (float)s[f];
-        if constexpr (LOCKSTEP) store_state<F>(b, p.n, i, s);
+        if constexpr (LOCKSTEP) store_state<F>(b, i, s, o, p.error_flag);
         store_obs(b.obs, i, o);
         b.counter[i] = CounterWord<KIND>::pack(0, (KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE) ? 1u : 0u, false, false);
         b.reward[i] = 0.f;
@@ -528,7 +601,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepParams p, con
     double ep[3] = {0.0, 0.0, 0.0};
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * kBlock) {
         T s[F];
-        if constexpr (LOCKSTEP) load_state<F>(b, p.n, i, s); else load_obs(b.obs, i, s);
+        if constexpr (LOCKSTEP) load_state<F>(b, i, s); else load_obs(b.obs, i, s);
         const uint32_t w = b.counter[i];
         int t = CounterWord<KIND>::steps_now(w);
         uint32_t cursor = CounterWord<KIND>::cursor(w);
@@ -569,7 +642,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepParams p, con
         float o[F];
 #pragma unroll
         for (int f = 0; f < F; f++) o[f] = (float)s[f];
-        if constexpr (LOCKSTEP) store_state<F>(b, p.n, i, s);
+        if constexpr (LOCKSTEP) store_state<F>(b, i, s, o, p.error_flag);
         store_obs(b.obs, i, o);
         b.counter[i] = rec;
         b.reward[i] = reward;
@@ -605,6 +678,24 @@ __global__ __launch_bounds__(kBlock) void decode_counter_kernel(const uint32_t* 
         if (trunc) trunc[i] = fin && (w & 0x40000000u) ? 1 : 0;
         if (ret) ret[i] = (float)l * EnvTraits<KIND>::step_reward;   // ClipReward maps +-1 to itself (clip_reward.h:22-24)
         if (cursor) cursor[i] = (int32_t)CounterWord<KIND>::cursor(w);
+    }
+}
+
+// Exact double state rows [N][F] (LOCKSTEP: obs + residual joined; F32: obs widened) for checkers and checkpoints.
+template <int F, bool LOCKSTEP>
+__global__ __launch_bounds__(kBlock) void read_state_kernel(const StepBuffers b, int64_t n, double* out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        double s[F];
+        if constexpr (LOCKSTEP) {
+            load_state<F>(b, i, s);
+        } else {
+            float o[F];
+            load_obs(b.obs, i, o);
+#pragma unroll
+            for (int f = 0; f < F; f++) s[f] = (double)o[f];
+        }
+#pragma unroll
+        for (int f = 0; f < F; f++) out[i * F + f] = s[f];
     }
 }
 
@@ -655,7 +746,7 @@ Layout make_layout(const gymhip_config& c) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
     L.obs = take(n * F * 4);
-    L.state = lock ? take(n * F * 8) : L.obs;
+    L.state = lock ? take(n * F * 4) : L.obs;   // LOCKSTEP: int32 residual rows (split-double), else the obs rows
     L.obs_norm = (c.wrappers & GYMHIP_WRAP_NORM_OBS) ? take(n * F * 4) : (size_t)-1;
     L.reward = take(n * 4);
     L.done = take(n * 4);
@@ -1041,6 +1132,25 @@ int gymhip_decode_counters(gymhip_engine* h, int32_t* elapsed_steps, int32_t* ep
         hipLaunchKernelGGL(decode_counter_kernel<KIND_CARTPOLE>, dim3(h->grid), dim3(kBlock), 0, (hipStream_t)stream, c, h->cfg.n_envs, elapsed_steps, episode_length, truncated, episode_return, tape_cursor);
     else
         hipLaunchKernelGGL(decode_counter_kernel<KIND_MOUNTAINCAR>, dim3(h->grid), dim3(kBlock), 0, (hipStream_t)stream, c, h->cfg.n_envs, elapsed_steps, episode_length, truncated, episode_return, tape_cursor);
+    HIP_TRY(hipGetLastError());
+    return GYMHIP_OK;
+}
+
+int gymhip_read_state_f64(gymhip_engine* h, double* state_out, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (!state_out) return fail(GYMHIP_EINVAL, "state_out is null");
+    if (!h->did_reset) return fail(GYMHIP_ESTATE, "state read before reset");
+    const StepParams p = make_params(h);
+    const bool lock = h->cfg.precision == GYMHIP_PRECISION_LOCKSTEP_F64;
+    dim3 g(h->grid), bdim(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (h->F == 4) {
+        if (lock) hipLaunchKernelGGL((read_state_kernel<4, true>), g, bdim, 0, s, p.buf, p.n, state_out);
+        else hipLaunchKernelGGL((read_state_kernel<4, false>), g, bdim, 0, s, p.buf, p.n, state_out);
+    } else {
+        if (lock) hipLaunchKernelGGL((read_state_kernel<2, true>), g, bdim, 0, s, p.buf, p.n, state_out);
+        else hipLaunchKernelGGL((read_state_kernel<2, false>), g, bdim, 0, s, p.buf, p.n, state_out);
+    }
     HIP_TRY(hipGetLastError());
     return GYMHIP_OK;
 }

@@ -77,10 +77,14 @@ class Engine:
         self.norm_stats = self._view(b.norm_stats, torch.float32, (2 * F + 4,))
         self.moments = self._view(b.moments, torch.float64, (self.moments_len,))
         self.episode_totals = self._view(b.episode_totals, torch.float64, (3,))
-        if cfg.precision == L.PRECISION_LOCKSTEP_F64:
-            self.state64 = self._view(b.state, torch.float64, (F // 2, n, 2))   # double2 planes
-        else:
-            self.state64 = None
+        # LOCKSTEP: int32 residual rows of the split-double state (gymhip.h); state_f64() joins them with obs
+        self.state_residual = self._view(b.state, torch.int32, (n, F)) if cfg.precision == L.PRECISION_LOCKSTEP_F64 else None
+
+    def state_f64(self):
+        """The envs' state as the reference holds it (double m_State rows [N, F]); exact in LOCKSTEP mode."""
+        out = torch.empty((self.cfg.n_envs, self.F), dtype=torch.float64, device=self.device)
+        L.check(self.lib.gymhip_read_state_f64(self.h, C.c_void_p(out.data_ptr()), self._stream()), "gymhip_read_state_f64")
+        return out
 
     def _view(self, ptr, dtype, shape):
         if not ptr:

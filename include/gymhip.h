@@ -64,8 +64,12 @@ typedef struct gymhip_config {
 typedef struct gymhip_buffers {
     int32_t obs_dim;
     int32_t moments_len;            /* doubles in `moments` */
-    void* state;                    /* LOCKSTEP: double2 planes [F/2][N]; F32: same memory as obs */
-    float* obs;                     /* f32 [N][F] raw observation after auto-reset (VecNormalize::oldObs) */
+    void* state;                    /* LOCKSTEP: i32 [N][F] residuals k of the split-double state — the reference's double
+                                       m_State element (cartpole.h:41, mountain_car.h:52) is exactly
+                                       (double)obs + k * 2^(e-53), e = obs' unbiased exponent; gymhip_read_state_f64()
+                                       joins the halves.  F32: same memory as obs */
+    float* obs;                     /* f32 [N][F] raw observation after auto-reset (VecNormalize::oldObs).  It is also the
+                                       high half of the state: read-only for callers */
     float* obs_norm;                /* f32 [N][F] normalised observation (NORM_OBS) */
     float* reward;                  /* f32 [N]  (normalised in place when NORM_REWARD) */
     float* done;                    /* f32 [N]  0/1 — the reference's done tensor is float32 (sync_env.h:102,110) */
@@ -144,11 +148,16 @@ int gymhip_rollout(gymhip_engine* h, const uint8_t* action_tape, int64_t k_steps
 int gymhip_decode_counters(gymhip_engine* h, int32_t* elapsed_steps, int32_t* episode_length, uint8_t* truncated,
                            float* episode_return, int32_t* tape_cursor, void* stream);
 
+/* The envs' state as the reference holds it: f64 [N][F] device rows, (x, x_dot, theta, theta_dot) = CartPoleEnv::m_State
+ * (cartpole.h:41) or (m_CarPos, m_CarVel) (mountain_car.h:52).  LOCKSTEP: exact; F32: the float state widened. */
+int gymhip_read_state_f64(gymhip_engine* h, double* state_out, void* stream);
+
 /* Reduce the per-block episode counters into episode_totals (device) and, if `host_out` is non-NULL, copy the three
  * doubles back (synchronises `stream`).  Monitor getters monitor.h:104-107 in aggregate form. */
 int gymhip_episode_stats(gymhip_engine* h, double* host_out, void* stream);
 /* Sticky device error word: bit0 = reset tape exhausted (an env needed more episodes than were uploaded; rows wrap),
- * bit1 = an env's tape-cursor field overflowed (2^20 episodes). */
+ * bit1 = an env's tape-cursor field overflowed (2^20 episodes), bit2 = a LOCKSTEP state value left the split-double
+ * range (non-finite, or nonzero below 2^-126 — the dynamics never produce either). */
 int gymhip_poll_error(gymhip_engine* h, int32_t* host_out, void* stream);
 
 /* VecNormalize::save/load state (vec_normalize.h:79-108; running_mean_std.h:28-40) as 2F+4 floats, host side. */

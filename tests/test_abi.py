@@ -56,8 +56,8 @@ def test_workspace_bytes_and_invalid_config():
     lib = L.load()
     c = EngineConfig(env_kind=L.ENV_CARTPOLE, n_envs=65536, precision=L.PRECISION_LOCKSTEP_F64).to_c()
     nbytes = lib.gymhip_workspace_bytes(C.byref(c))
-    # state f64 32 B + obs 16 B + reward 4 + done 4 + counter 4 = 60 B/env plus small fixed buffers
-    assert 60 * 65536 <= nbytes <= 60 * 65536 + (1 << 21)
+    # split-double state: obs 16 B + residuals 16 B; reward 4 + done 4 + counter 4 = 44 B/env plus small fixed buffers
+    assert 44 * 65536 <= nbytes <= 44 * 65536 + (1 << 21)
     c32 = EngineConfig(env_kind=L.ENV_CARTPOLE, n_envs=65536, precision=L.PRECISION_F32).to_c()
     assert lib.gymhip_workspace_bytes(C.byref(c32)) < nbytes          # obs aliases the state
     bad = EngineConfig(n_envs=0).to_c()

@@ -88,8 +88,7 @@ def test_hip_reproduces_cartpole_golden():
         assert np.array_equal(np.packbits(np.stack(trunc), axis=1), g["truncated"])
         for k, t in enumerate(g["obs_at"]):
             assert np.allclose(obs[int(t)], g["obs"][k], rtol=1e-5, atol=1e-7)
-        st = eng.state64.cpu().numpy()
-        assert np.abs(np.concatenate([st[0], st[1]], axis=1) - g["final_obs64"]).max() <= 1e-12
+        assert np.abs(eng.state_f64().cpu().numpy() - g["final_obs64"]).max() <= 1e-12
 
 
 @pytest.mark.gpu

@@ -68,9 +68,11 @@ def test_cartpole_step_api_lockstep_every_step(oracle):
             check_episode_info(eng, r, d)
         if t % 250 == 0 or t == T - 1:
             # the fp64 state itself: bit-exact unless device sin/cos round differently from glibc (then <= 1e-12)
-            st = eng.state64.cpu().numpy()                      # [2][n][2] double2 planes
-            g64 = np.concatenate([st[0], st[1]], axis=1)        # [n][4]
+            g64 = eng.state_f64().cpu().numpy()                 # [n][4], split-double halves joined on the device
             assert np.abs(g64 - r["obs64"]).max() <= 1e-12
+            assert np.array_equal(g64.astype(np.float32), g_obs)   # obs IS the high half of the state
+            # the split-double store is lossless: a lossy one would leave (almost) no value bit-identical to the oracle's
+            assert (g64 == r["obs64"]).mean() >= 0.999
     assert n_done > n * T / 40            # episodes did end (mean length ~22)
     assert eng.poll_error() == 0
     tot = eng.episode_stats()
@@ -106,8 +108,7 @@ def test_cartpole_config2_rollout_65536x10000(oracle):
         if last:
             assert rel_err(rec_obs.cpu().numpy(), r["obs"]).max() <= REL
         episodes += int(r["done"].sum())
-    st = eng.state64.cpu().numpy()
-    assert np.abs(np.concatenate([st[0], st[1]], axis=1) - r["final_obs64"]).max() <= 1e-12
+    assert np.abs(eng.state_f64().cpu().numpy() - r["final_obs64"]).max() <= 1e-12
     assert eng.poll_error() == 0
     assert eng.episode_stats()[0] == episodes
 
