@@ -95,6 +95,7 @@ struct CartPoleC {  // cartpole.h:30-39 — float constants
 // GYMHIP_DIAG (tools/sweep_variants.sh only; never defined in the shipped library — results are WRONG when it is set):
 //   1 = trivial dynamics, no env ever done: the pure cost of the kernel's HBM streams
 //   2 = sin/cos replaced by two-term polynomials      3 = float divides replaced by reciprocal multiplies
+//   4 = the device library's sincos instead of pole_sincos (results stay right; A/B timing only)
 #ifndef GYMHIP_DIAG
 #define GYMHIP_DIAG 0
 #endif
@@ -104,6 +105,29 @@ __device__ inline float diag_div(float a, float b) {
 #else
     return a / b;
 #endif
+}
+
+// sin and cos of the pole angle in double.  At step entry |theta| <= theta_thr (0.2095 rad) always holds: a step that
+// leaves the range ends the episode and the state is replaced by a reset draw.  Below 0.3 rad no argument reduction is
+// needed and the classic fdlibm kernels (k_sin.c / k_cos.c minimax coefficients, error < 1 ulp — the class of accuracy
+// glibc's and the device library's sin/cos have) apply directly: ~25 fp64 instructions instead of the ~170 of the
+// device library's sincos with its Cody-Waite/Payne-Hanek reduction.  Only the float-rounded values are used
+// (cartpole.cpp:39-40), so two < 1 ulp doubles agree after rounding except within ~2^-29 relative of a float tie.
+// Anything else falls back to the device library.
+__device__ __attribute__((noinline)) double2 library_sincos(double x) { double2 r; r.x = sin(x); r.y = cos(x); return r; }
+__device__ inline void pole_sincos(double x, double* sn, double* cs) {
+    if (__builtin_expect(__builtin_fabs(x) < 0.3, 1)) {
+        const double z = x * x;
+        const double rs = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                     -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+        *sn = fma(z * x, fma(z, rs, -1.66666666666666324348e-01), x);
+        const double rc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                                  2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+        *cs = 1.0 - (0.5 * z - z * rc);
+    } else {
+        const double2 r = library_sincos(x);   // out of line: keeps its registers and code off the hot path
+        *sn = r.x; *cs = r.y;
+    }
 }
 
 // cartpole.cpp:33-68, exact precisions (A1).  Returns the env's own `done`.
@@ -118,8 +142,10 @@ __device__ inline bool cartpole_step(double (&s)[4], int action, int time_step) 
     double sd, cd;
 #if GYMHIP_DIAG == 2
     sd = theta - theta * theta * theta * (1.0 / 6.0); cd = 1.0 - theta * theta * 0.5;
+#elif GYMHIP_DIAG == 4
+    sincos(theta, &sd, &cd);      // the device library's sincos, for A/B runs against pole_sincos
 #else
-    sincos(theta, &sd, &cd);
+    pole_sincos(theta, &sd, &cd);
 #endif
     float cos_t = (float)cd, sin_t = (float)sd;
     float temp = diag_div((float)((double)force + ((double)C::polemass_length * (theta_dot * theta_dot)) * (double)sin_t), C::total_mass);
@@ -222,13 +248,14 @@ template <> struct EnvTraits<KIND_MOUNTAINCAR> { static constexpr int F = 2; sta
 // int32 residual rows [N][F] that complete each float to the exact double (split-double, below).
 // ------------------------------------------------------------------------------------------------------------
 // Compile-time tuning knobs (profiles/ and DESIGN.md §5 record what each is worth on MI355X):
-//   GYMHIP_ILP  envs per thread per grid-stride iteration, all loads issued before the first dependent use
 //   GYMHIP_NT   1 = non-temporal loads/stores on the once-per-step streams (working set >> 256 MiB Infinity Cache)
-#ifndef GYMHIP_ILP
-#define GYMHIP_ILP 1
-#endif
 #ifndef GYMHIP_NT
 #define GYMHIP_NT 1
+#endif
+//   GYMHIP_PIPE 1 = software-pipelined step loop (iteration k+1's loads in flight under iteration k's gather + stores)
+// (An earlier knob, several envs per thread per iteration, was worth < 1 % and is gone: profiles/r01_sweep.txt.)
+#ifndef GYMHIP_PIPE
+#define GYMHIP_PIPE 1
 #endif
 using f32x4 = float __attribute__((ext_vector_type(4)));
 using f32x2 = float __attribute__((ext_vector_type(2)));
@@ -265,20 +292,20 @@ __device__ inline void store_i32(int32_t* a, int64_t i, const int32_t (&k)[2]) {
 // 8 B per state element become 4 B beyond the obs row that is written anyway.  Not representable: nonzero |d| < 2^-126
 // and non-finite d; the dynamics cannot produce either (every value is a short sum of terms >= 2^-80 in magnitude),
 // and bit 2 of the error flag reports it if it ever happens.
-__device__ inline int32_t split_residual(double d, float f, int32_t* error_flag) {
+// Both are branch-free (selects): they run four times per env-step on the hot path.
+__device__ inline int32_t split_residual(double d, float f, bool& out_of_range) {
     const int e = (int)((__float_as_uint(f) >> 23) & 0xffu);
-    if (e == 0 || e == 255) {
-        if (d != 0.0) atomicOr(error_flag, 4);
-        return 0;
-    }
-    const double scale = __longlong_as_double((long long)(1023 + 180 - e) << 52);   // 2^(53 - (e - 127))
-    return (int32_t)((d - (double)f) * scale);
+    const bool bad = e == 0 || e == 255;                     // f is zero/subnormal or non-finite: no residual
+    out_of_range |= bad && d != 0.0;
+    const double scale = __longlong_as_double((long long)(1023 + 180 - e) << 52);   // 2^(53 - (e - 127)), finite for any e
+    const int32_t k = (int32_t)((d - (double)f) * scale);
+    return bad ? 0 : k;
 }
 __device__ inline double split_join(float f, int32_t k) {
     const int e = (int)((__float_as_uint(f) >> 23) & 0xffu);
-    if (e == 0 || e == 255) return (double)f;
-    const double inv = __longlong_as_double((long long)(1023 - 180 + e) << 52);     // 2^((e - 127) - 53)
-    return (double)f + (double)k * inv;
+    const double inv = __longlong_as_double((long long)(1023 - 180 + e) << 52);     // 2^((e - 127) - 53), finite for any e
+    const double hi = (double)f;
+    return k == 0 ? hi : hi + (double)k * inv;               // k == 0 keeps -0.0 and the e = 0 / 255 cases untouched
 }
 template <int F> __device__ inline void join_state(const float (&o)[F], const int32_t (&k)[F], double (&s)[F]) {
 #pragma unroll
@@ -293,8 +320,10 @@ template <int F> __device__ inline void load_state(const StepBuffers& b, int64_t
 // Stores the residual half; the caller stores o (= the float-rounded state) through store_obs.
 template <int F> __device__ inline void store_state(const StepBuffers& b, int64_t i, const double (&s)[F], const float (&o)[F], int32_t* error_flag) {
     int32_t k[F];
+    bool out_of_range = false;
 #pragma unroll
-    for (int f = 0; f < F; f++) k[f] = split_residual(s[f], o[f], error_flag);
+    for (int f = 0; f < F; f++) k[f] = split_residual(s[f], o[f], out_of_range);
+    if (out_of_range) atomicOr(error_flag, 4);
     store_i32((int32_t*)b.state, i, k);
 }
 
@@ -367,87 +396,99 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
     const bool tape_mode = KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE;
     const bool ret_lane = (p.wrappers & GYMHIP_WRAP_NORM_REWARD) && (p.wrappers & GYMHIP_WRAP_NORM_TRAINING);
 
-    constexpr int U = GYMHIP_ILP;
-    for (int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x; base < p.n; base += (int64_t)gridDim.x * (kBlock * U)) {
-        // phase 1: every load of the U envs this thread owns is issued before the first dependent instruction
-        float ov[U][F];
-        int32_t kv[U][LOCKSTEP ? F : 1];
-        int action_v[U];
-        uint32_t w_v[U];
-        float ret_v[U];
+    // Everything one env-step reads, as raw registers: the loads are issued as a batch and nothing depends on them
+    // until the next iteration's dynamics start.
+    struct Inputs {
+        float o[F];
+        int32_t k[LOCKSTEP ? F : 1];
+        int action;
+        uint32_t w;       // packed step counter / episode record / tape cursor (gymhip.h)
+        float ret;
+    };
+    // `i` must be a valid env index: the loads are unconditional so that the compiler can count them (a lane with no
+    // next iteration re-reads its own, cached, inputs and discards them).
+    auto issue_loads = [&](int64_t i, Inputs& in) {
+        load_obs(b.obs, i, in.o);
+        if constexpr (LOCKSTEP) load_i32((const int32_t*)b.state, i, in.k);
+        in.action = (int)ld_stream(actions + i);
+        in.w = ld_stream(b.counter + i);
+        if constexpr (NORM) in.ret = ret_lane ? ld_stream(b.returns + i) : 0.f;
+    };
+
+    // Software pipeline: iteration k+1's loads are issued before iteration k's arithmetic, so they are in flight under
+    // the dynamics (~500 VALU instructions) and the stores.  Measured on MI355X (16.7 M envs, lockstep): COUNTER_RNG
+    // resets 0.282 -> 0.270 ms; TAPE resets unchanged at 0.284 ms — there the reset-tape gather's over-fetch (a 16-B row
+    // per done env drags in a whole memory burst) sets the time, not latency.  Issuing the gather BEFORE the next loads
+    // (so that, with the in-order vmcnt counter, its wait would not cover them) was tried and is slower for both.
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    Inputs cur, nxt;
+    issue_loads(i < p.n ? i : p.n - 1, cur);
+    for (; i < p.n; i += stride) {
+#if GYMHIP_PIPE
+        issue_loads(i + stride < p.n ? i + stride : i, nxt);
+#else
+        if (i != (int64_t)blockIdx.x * kBlock + threadIdx.x) issue_loads(i, cur);
+#endif
+        T s[F];
+        if constexpr (LOCKSTEP) {
+            join_state<F>(cur.o, cur.k, s);
+        } else {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int64_t i = base + (int64_t)u * kBlock;
-            if (i < p.n) {
-                load_obs(b.obs, i, ov[u]);
-                if constexpr (LOCKSTEP) load_i32((const int32_t*)b.state, i, kv[u]);
-                action_v[u] = (int)ld_stream(actions + i);
-                w_v[u] = ld_stream(b.counter + i);   // packed step counter / episode record / tape cursor (gymhip.h)
-                if constexpr (NORM) ret_v[u] = ret_lane ? ld_stream(b.returns + i) : 0.f;
-            }
+            for (int f = 0; f < F; f++) s[f] = cur.o[f];
         }
-        // phase 2: dynamics + fused wrappers + auto-reset + stores
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int64_t i = base + (int64_t)u * kBlock;
-            if (i >= p.n) continue;
-            T s[F];
-            if constexpr (LOCKSTEP) {
-                join_state<F>(ov[u], kv[u], s);
+        const int action = cur.action;
+        const uint32_t w = cur.w;
+        int t = CounterWord<KIND>::steps_now(w);
+        uint32_t cursor = CounterWord<KIND>::cursor(w);
+
+        bool env_done;
+        if constexpr (KIND == KIND_CARTPOLE) env_done = cartpole_step(s, action, t); else env_done = mountaincar_step(s, action);
+        t += 1;
+        bool done = env_done, trunc = false;
+        if (time_limit && t >= p.max_episode_steps) { trunc = !env_done; done = true; }   // time_limit.h:30-34
+        float reward = EnvTraits<KIND>::step_reward;
+        if (clip) reward = reward == 0.f ? reward : (reward > 0.f ? 1.f : -1.f);           // clip_reward.h:22-24
+
+        if (done) {
+            // Monitor (monitor.h:78-97): every step of these envs pays the same reward, so the ordered float sum
+            // of t copies equals float(t)*reward exactly (t < 2^24).  The finished episode's (length, truncated)
+            // and the reset-tape cursor live in the counter word, which is rewritten every step anyway: no extra
+            // HBM traffic and no scattered read-modify-write on the done path.
+            ep[0] += 1.0; ep[1] += (double)((float)t * reward); ep[2] += (double)t;
+            int64_t e;
+            if (tape_mode) {
+                e = cursor;
+                if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
+                cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
             } else {
-#pragma unroll
-                for (int f = 0; f < F; f++) s[f] = ov[u][f];
+                e = p.step_counter;            // stateless: (seed, env, global step) is unique per reset
             }
-            const int action = action_v[u];
-            const uint32_t w = w_v[u];
-            int t = CounterWord<KIND>::steps_now(w);
-            uint32_t cursor = CounterWord<KIND>::cursor(w);
+            reset_state<KIND, T>(p, i, e, s);   // sync_env.h:92-100: terminal obs replaced by the reset obs
+        }
 
-            bool env_done;
-            if constexpr (KIND == KIND_CARTPOLE) env_done = cartpole_step(s, action, t); else env_done = mountaincar_step(s, action);
-            t += 1;
-            bool done = env_done, trunc = false;
-            if (time_limit && t >= p.max_episode_steps) { trunc = !env_done; done = true; }   // time_limit.h:30-34
-            float reward = EnvTraits<KIND>::step_reward;
-            if (clip) reward = reward == 0.f ? reward : (reward > 0.f ? 1.f : -1.f);           // clip_reward.h:22-24
-
-            if (done) {
-                // Monitor (monitor.h:78-97): every step of these envs pays the same reward, so the ordered float sum
-                // of t copies equals float(t)*reward exactly (t < 2^24).  The finished episode's (length, truncated)
-                // and the reset-tape cursor live in the counter word, which is rewritten every step anyway: no extra
-                // HBM traffic and no scattered read-modify-write on the done path.
-                ep[0] += 1.0; ep[1] += (double)((float)t * reward); ep[2] += (double)t;
-                int64_t e;
-                if (tape_mode) {
-                    e = cursor;
-                    if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
-                    cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
-                } else {
-                    e = p.step_counter;            // stateless: (seed, env, global step) is unique per reset
-                }
-                reset_state<KIND, T>(p, i, e, s);   // sync_env.h:92-100: terminal obs replaced by the reset obs
-            }
-
-            float o[F];
+        float o[F];
 #pragma unroll
-            for (int f = 0; f < F; f++) o[f] = (float)s[f];
-            if constexpr (LOCKSTEP) store_state<F>(b, i, s, o, p.error_flag);
-            store_obs(b.obs, i, o);
-            st_stream(b.counter + i, CounterWord<KIND>::pack(t, cursor, done, trunc));
-            st_stream(b.reward + i, reward);
-            st_stream(b.done + i, done ? 1.f : 0.f);
+        for (int f = 0; f < F; f++) o[f] = (float)s[f];
+        if constexpr (LOCKSTEP) store_state<F>(b, i, s, o, p.error_flag);
+        store_obs(b.obs, i, o);
+        st_stream(b.counter + i, CounterWord<KIND>::pack(t, cursor, done, trunc));
+        st_stream(b.reward + i, reward);
+        st_stream(b.done + i, done ? 1.f : 0.f);
 
-            if constexpr (NORM) {
+        if constexpr (NORM) {
 #pragma unroll
-                for (int f = 0; f < F; f++) { double d = (double)o[f] - (double)shift[f]; acc[f] += d; acc[F + f] += d * d; }
-                if (ret_lane) {
-                    float r = ret_v[u] * p.gamma + reward;            // vec_normalize.h:132
-                    double d = (double)r - (double)shift[F];
-                    acc[2 * F] += d; acc[2 * F + 1] += d * d;
-                    st_stream(b.returns + i, done ? 0.f : r);         // vec_normalize.h:175 (applied after the RMS update)
-                }
+            for (int f = 0; f < F; f++) { double d = (double)o[f] - (double)shift[f]; acc[f] += d; acc[F + f] += d * d; }
+            if (ret_lane) {
+                float r = cur.ret * p.gamma + reward;              // vec_normalize.h:132
+                double d = (double)r - (double)shift[F];
+                acc[2 * F] += d; acc[2 * F + 1] += d * d;
+                st_stream(b.returns + i, done ? 0.f : r);         // vec_normalize.h:175 (applied after the RMS update)
             }
         }
+#if GYMHIP_PIPE
+        cur = nxt;
+#endif
     }
 
     if constexpr (NORM) {
@@ -734,7 +775,7 @@ bool valid_config(const gymhip_config* c) {
 int grid_for(int64_t n) {
     int64_t cap = kDefaultGrid;
     if (const char* e = getenv("GYMHIP_GRID")) { int v = atoi(e); if (v > 0 && v <= kMaxGrid) cap = v; }
-    int64_t g = (n + (int64_t)kBlock * GYMHIP_ILP - 1) / ((int64_t)kBlock * GYMHIP_ILP);
+    int64_t g = (n + kBlock - 1) / kBlock;
     return (int)(g < cap ? g : cap);
 }
 
