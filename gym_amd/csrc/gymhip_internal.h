@@ -10,7 +10,7 @@ int fail(int code, const char* fmt, ...);
 
 // Per-env device arrays (N = n_envs, F = obs_dim).  See include/gymhip.h gymhip_buffers for meanings.
 struct StepBuffers {
-    void* state;             // LOCKSTEP: double2 planes [F/2][N]; F32: == obs
+    void* state;             // LOCKSTEP: i32 [N][F] split-double residuals; F32: == obs
     float* obs;              // f32 [N][F]
     float* reward;           // f32 [N]
     float* done;             // f32 [N]
