@@ -107,6 +107,10 @@ SIGNATURES = {
     "gymhip_atari_reset": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_step": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gymhip_atari_preprocess": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "gymhip_atari_set_palette": (C.c_int, [_vp, _vp]),
+    "gymhip_atari_preprocess_indexed": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "gymhip_atari_reset_indexed": (C.c_int, [_vp, _vp, _vp]),
+    "gymhip_atari_step_indexed": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gymhip_atari_materialize_nhwc": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_materialize_nchw_f32": (C.c_int, [_vp, _vp, _vp]),
 }

@@ -43,20 +43,34 @@ class AtariPreprocessor:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def set_palette(self, zrgb256):
+        """The emulator's colour table: 256 words 0x00RRGGBB (the reference's rgb_palette, atari_ntsc_rgb_palette.h).
+        After this, preprocess/reset/step also accept index screens uint8 [N, 2, H, W] (ale getScreen().getArray())."""
+        import numpy as np
+        pal = np.ascontiguousarray(zrgb256, dtype=np.uint32)
+        if pal.shape != (256,):
+            raise ValueError("palette must hold 256 entries")
+        L.check(self.lib.gymhip_atari_set_palette(self.h, pal.ctypes.data_as(C.c_void_p)), "gymhip_atari_set_palette")
+
     def _frames(self, frames: torch.Tensor):
-        want = (self.n, 2, self.src_hw[0], self.src_hw[1], 3)
-        if frames.dtype != torch.uint8 or tuple(frames.shape) != want or not frames.is_contiguous() or frames.device != self.device:
-            raise ValueError(f"frames must be a contiguous uint8 {want} tensor on {self.device}")
-        return C.c_void_p(frames.data_ptr())
+        """-> (device pointer, indexed?).  RGB frames are [N, 2, H, W, 3]; index screens [N, 2, H, W]."""
+        rgb = (self.n, 2, self.src_hw[0], self.src_hw[1], 3)
+        if frames.dtype != torch.uint8 or tuple(frames.shape) not in (rgb, rgb[:-1]) or not frames.is_contiguous() or frames.device != self.device:
+            raise ValueError(f"frames must be a contiguous uint8 {rgb} (RGB) or {rgb[:-1]} (palette index) tensor on {self.device}")
+        return C.c_void_p(frames.data_ptr()), frames.dim() == 4
 
     def preprocess(self, frames: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         if out is None:
             out = torch.empty((self.n, *self.dst_hw), dtype=torch.uint8, device=self.device)
-        L.check(self.lib.gymhip_atari_preprocess(self.h, self._frames(frames), C.c_void_p(out.data_ptr()), self._stream()), "gymhip_atari_preprocess")
+        ptr, indexed = self._frames(frames)
+        fn = self.lib.gymhip_atari_preprocess_indexed if indexed else self.lib.gymhip_atari_preprocess
+        L.check(fn(self.h, ptr, C.c_void_p(out.data_ptr()), self._stream()), "gymhip_atari_preprocess")
         return out
 
     def reset(self, frames: torch.Tensor):
-        L.check(self.lib.gymhip_atari_reset(self.h, self._frames(frames), self._stream()), "gymhip_atari_reset")
+        ptr, indexed = self._frames(frames)
+        fn = self.lib.gymhip_atari_reset_indexed if indexed else self.lib.gymhip_atari_reset
+        L.check(fn(self.h, ptr, self._stream()), "gymhip_atari_reset")
 
     def step(self, frames: torch.Tensor, done: torch.Tensor | None = None):
         dp = None
@@ -64,7 +78,9 @@ class AtariPreprocessor:
             if done.dtype != torch.uint8 or done.numel() != self.n or not done.is_contiguous():
                 raise ValueError("done must be a contiguous uint8 [n_envs] tensor")
             dp = C.c_void_p(done.data_ptr())
-        L.check(self.lib.gymhip_atari_step(self.h, self._frames(frames), dp, self._stream()), "gymhip_atari_step")
+        ptr, indexed = self._frames(frames)
+        fn = self.lib.gymhip_atari_step_indexed if indexed else self.lib.gymhip_atari_step
+        L.check(fn(self.h, ptr, dp, self._stream()), "gymhip_atari_step")
 
     def head(self) -> int:
         ring, head = C.c_void_p(), C.c_int32()

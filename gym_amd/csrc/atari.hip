@@ -35,6 +35,10 @@ constexpr int kFrameBlock = 512;  // one workgroup per frame: 8 waves; 4 workgro
 #ifndef GYMHIP_ATARI_WAVES
 #define GYMHIP_ATARI_WAVES 6   // min waves/SIMD: 80 VGPRs -> 3 frames (24 waves) per CU; 4 = 4.67 TB/s, 6 = 5.14, 8 spills = 3.5 (profiles/r01_sweep.txt)
 #endif
+// GYMHIP_ATARI_DIAG (timing experiments only, results WRONG): 1 = phase 1 only (no resize), 2 = no colour-table lookups
+#ifndef GYMHIP_ATARI_DIAG
+#define GYMHIP_ATARI_DIAG 0
+#endif
 constexpr int kMaxT = 4;        // taps per destination index in the padded tables (zero-weight padding)
 
 #define HIP_TRY(expr)                                                                             \
@@ -76,7 +80,8 @@ AxisTable make_axis_table(int ssize, int dsize) {
 }
 
 struct AtariParams {
-    const uint8_t* frames;     // u8 [N][2][H][W][3]
+    const uint8_t* frames;     // RGB24: u8 [N][2][H][W][3]; INDEX8: u8 [N][2][H][W] palette indices
+    const uint32_t* lut;       // INDEX8: 256 colours packed R | G<<8 | B<<16 (device)
     uint8_t* out;              // plane of env e starts at out + e * env_stride + slot_offset
     int64_t env_stride;
     int64_t slot_offset;
@@ -118,23 +123,69 @@ __device__ inline u32x3 load_px4(const uint32_t* base, int j) {
     return v;
 }
 
-template <int GRAY15, int NT>
+// SRC: 0 = RGB24 frames (AtariEnv::getObs output, atari_env.cpp:11-17); 1 = INDEX8 screens, the emulator's native palette
+// indices (ale->getScreen().getArray()), coloured in-kernel by the 256-entry table getScreenRGB2 applies on the host
+// (atari/ale_c_wrapper.cpp:28-41): a third of the bytes over PCIe and out of HBM, identical pixels.
+template <int GRAY15, int NT, int SRC>
 __global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preprocess_kernel(const AtariParams p) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int HW = p.H * p.W;
     uint8_t* gray = lds;                                           // [H*W] u8
     int32_t* ysi = (int32_t*)(lds + ((HW + 15) & ~15));            // [dh][kMaxT]
     float* yal = (float*)(ysi + p.dh * kMaxT);                     // [dh][kMaxT]
+    uint32_t* lut = (uint32_t*)(yal + p.dh * kMaxT);               // [256] (INDEX8)
     const int tid = threadIdx.x;
     const int64_t e = blockIdx.x;
 
     for (int k = tid; k < p.dh * kMaxT; k += kFrameBlock) { ysi[k] = p.ysi[k]; yal[k] = p.yal[k]; }
 
     // ---- phase 1: max of the two frames -> gray -> LDS ---------------------------------------------------------
+    uint32_t* gray32 = (uint32_t*)gray;
+    if constexpr (SRC == 1) {
+        // One 4-B table entry per colour (bytes R, G, B): measured against an 8-B entry {R | G << 16, B*wB + round} that
+        // turns max + gray into pk_max + max + v_dot2_u32_u16, the smaller entry wins (0.132 vs 0.218 ms at 4096 envs,
+        // random indices): the table lookups, not the arithmetic, bound this phase, and an 8-B entry doubles them.
+        if (tid < 256) lut[tid] = p.lut[tid];
+        __syncthreads();
+        using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
+        const u32x4* fa = (const u32x4*)(p.frames + e * 2 * (int64_t)HW);
+        const u32x4* fb = (const u32x4*)(p.frames + e * 2 * (int64_t)HW + (int64_t)HW);
+        const int items = HW / 16;                                 // 16 pixels (16 index bytes) per item
+        constexpr int UNR = 3;
+        for (int it = tid; it < items; it += kFrameBlock * UNR) {
+            u32x4 a[UNR], b[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int j = it + u * kFrameBlock;
+                if (j < items) { a[u] = __builtin_nontemporal_load(fa + j); b[u] = __builtin_nontemporal_load(fb + j); }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int j = it + u * kFrameBlock;
+                if (j >= items) continue;
+                u32x4 g;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const uint32_t ia = a[u][w], ib = b[u][w];
+                    uint32_t out = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+#if GYMHIP_ATARI_DIAG == 2
+                        const uint32_t m = max_u8x4((ia >> (8 * k)) * 0x010101u, (ib >> (8 * k)) * 0x010101u);
+#else
+                        const uint32_t m = max_u8x4(lut[(ia >> (8 * k)) & 255u], lut[(ib >> (8 * k)) & 255u]);   // cv::max of the two coloured pixels
+#endif
+                        out |= gray_px<GRAY15>(m & 255u, (m >> 8) & 255u, (m >> 16) & 255u) << (8 * k);
+                    }
+                    g[w] = out;
+                }
+                ((u32x4*)gray)[j] = g;
+            }
+        }
+    } else {
     const uint32_t* fa = (const uint32_t*)(p.frames + e * 2 * (int64_t)HW * 3);
     const uint32_t* fb = (const uint32_t*)(p.frames + e * 2 * (int64_t)HW * 3 + (int64_t)HW * 3);
     const int items = HW / 4;                                      // 4 pixels (12 B) per item
-    uint32_t* gray32 = (uint32_t*)gray;
     constexpr int UNR = 4;
     for (int it = tid; it < items; it += kFrameBlock * UNR) {
         u32x3 a[UNR], b[UNR];
@@ -156,6 +207,7 @@ __global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preproc
             gray32[j] = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
         }
     }
+    }
 
     // ---- phase 2: INTER_AREA out of LDS.  A thread owns 4 horizontally adjacent output columns (its 4 x NT x-taps stay
     // in registers) and walks down the rows; the 4 results leave as one 4-B store. -----------------------------------------
@@ -168,6 +220,10 @@ __global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preproc
         for (int k = 0; k < NT; k++) { xs[q][k] = p.xsi[(qx * 4 + q) * kMaxT + k]; xa[q][k] = p.xal[(qx * 4 + q) * kMaxT + k]; }
     __syncthreads();
     uint32_t* dst32 = (uint32_t*)(p.out + e * p.env_stride + p.slot_offset);
+#if GYMHIP_ATARI_DIAG == 1
+    if (tid < 8) dst32[tid] = gray32[tid * 64];
+    return;
+#endif
     if (ry < rows_per_pass) {
         for (int dy = ry; dy < p.dh; dy += rows_per_pass) {
             float sum[4];
@@ -258,6 +314,7 @@ struct gymhip_atari {
     int max_taps;
     size_t lds_bytes;
     bool did_reset;
+    uint32_t* lut;        // INDEX8 colour table (device, 256 entries R | G<<8 | B<<16) or null until gymhip_atari_set_palette
 };
 
 namespace {
@@ -277,23 +334,31 @@ template <typename T> int upload(const std::vector<T>& v, T** out) {
     return GYMHIP_OK;
 }
 
-int launch_preprocess(gymhip_atari* h, const uint8_t* frames, uint8_t* out, int64_t env_stride, int64_t slot_offset,
+template <int SRC>
+void launch_variant(gymhip_atari* h, const AtariParams& p, hipStream_t s) {
+    dim3 grid((unsigned)h->cfg.n_envs), block(kFrameBlock);
+    const bool g15 = h->cfg.gray_bits == 15;
+    if (h->max_taps <= 3) {
+        if (g15) hipLaunchKernelGGL((atari_preprocess_kernel<1, 3, SRC>), grid, block, h->lds_bytes, s, p);
+        else hipLaunchKernelGGL((atari_preprocess_kernel<0, 3, SRC>), grid, block, h->lds_bytes, s, p);
+    } else {
+        if (g15) hipLaunchKernelGGL((atari_preprocess_kernel<1, 4, SRC>), grid, block, h->lds_bytes, s, p);
+        else hipLaunchKernelGGL((atari_preprocess_kernel<0, 4, SRC>), grid, block, h->lds_bytes, s, p);
+    }
+}
+
+int launch_preprocess(gymhip_atari* h, bool indexed, const uint8_t* frames, uint8_t* out, int64_t env_stride, int64_t slot_offset,
                       const uint8_t* done, bool ring_dst, hipStream_t s) {
+    if (indexed && !h->lut) return fail(GYMHIP_ESTATE, "indexed frames need a colour table first (gymhip_atari_set_palette)");
+    if (indexed && ((int64_t)h->cfg.src_h * h->cfg.src_w) % 16) return fail(GYMHIP_EINVAL, "indexed screens must be a multiple of 16 bytes (210x160 is)");
     AtariParams p{};
+    p.lut = h->lut;
     p.frames = frames; p.out = out; p.env_stride = env_stride; p.slot_offset = slot_offset;
     p.done = done; p.ring = ring_dst ? h->ring : nullptr;
     p.xsi = h->xsi; p.xal = h->xal; p.ysi = h->ysi; p.yal = h->yal;
     p.H = h->cfg.src_h; p.W = h->cfg.src_w; p.dh = h->cfg.dst_h; p.dw = h->cfg.dst_w;
     p.n_stack = h->cfg.n_stack; p.slot = h->head; p.clear_on_done = h->cfg.clear_on_done;
-    dim3 grid((unsigned)h->cfg.n_envs), block(kFrameBlock);
-    const bool g15 = h->cfg.gray_bits == 15;
-    if (h->max_taps <= 3) {
-        if (g15) hipLaunchKernelGGL((atari_preprocess_kernel<1, 3>), grid, block, h->lds_bytes, s, p);
-        else hipLaunchKernelGGL((atari_preprocess_kernel<0, 3>), grid, block, h->lds_bytes, s, p);
-    } else {
-        if (g15) hipLaunchKernelGGL((atari_preprocess_kernel<1, 4>), grid, block, h->lds_bytes, s, p);
-        else hipLaunchKernelGGL((atari_preprocess_kernel<0, 4>), grid, block, h->lds_bytes, s, p);
-    }
+    if (indexed) launch_variant<1>(h, p, s); else launch_variant<0>(h, p, s);
     HIP_TRY(hipGetLastError());
     return GYMHIP_OK;
 }
@@ -325,7 +390,7 @@ int gymhip_atari_create(const gymhip_atari_config* cfg, int device, gymhip_atari
     h->cfg = *cfg; h->device = device; h->head = 0; h->did_reset = false;
     h->max_taps = std::max(xt.max_taps, yt.max_taps);
     const size_t hw = (size_t)cfg->src_h * cfg->src_w;
-    h->lds_bytes = ((hw + 15) & ~(size_t)15) + (sizeof(int32_t) + sizeof(float)) * cfg->dst_h * kMaxT;
+    h->lds_bytes = ((hw + 15) & ~(size_t)15) + (sizeof(int32_t) + sizeof(float)) * cfg->dst_h * kMaxT + 256 * sizeof(uint32_t);
     int rc = GYMHIP_OK;
     if (h->lds_bytes > 160 * 1024) rc = fail(GYMHIP_EINVAL, "gray frame + tables (%zu B) exceed the 160 KiB LDS of a CU", h->lds_bytes);
     if (!rc) rc = upload(xt.si, &h->xsi);
@@ -341,8 +406,10 @@ int gymhip_atari_create(const gymhip_atari_config* cfg, int device, gymhip_atari
         h->ring = (uint8_t*)p;
     }
     if (!rc && h->lds_bytes > 64 * 1024) {
-        const void* fns[] = {(const void*)atari_preprocess_kernel<1, 3>, (const void*)atari_preprocess_kernel<0, 3>,
-                             (const void*)atari_preprocess_kernel<1, 4>, (const void*)atari_preprocess_kernel<0, 4>};
+        const void* fns[] = {(const void*)atari_preprocess_kernel<1, 3, 0>, (const void*)atari_preprocess_kernel<0, 3, 0>,
+                             (const void*)atari_preprocess_kernel<1, 4, 0>, (const void*)atari_preprocess_kernel<0, 4, 0>,
+                             (const void*)atari_preprocess_kernel<1, 3, 1>, (const void*)atari_preprocess_kernel<0, 3, 1>,
+                             (const void*)atari_preprocess_kernel<1, 4, 1>, (const void*)atari_preprocess_kernel<0, 4, 1>};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess)
                 rc = fail(GYMHIP_EHIP, "cannot raise the dynamic LDS limit to %zu B", h->lds_bytes);
@@ -356,7 +423,7 @@ int gymhip_atari_destroy(gymhip_atari* h) {
     if (!h) return GYMHIP_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    void* ptrs[] = {h->ring, h->xsi, h->xal, h->ysi, h->yal};
+    void* ptrs[] = {h->ring, h->xsi, h->xal, h->ysi, h->yal, h->lut};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return GYMHIP_OK;
@@ -369,30 +436,53 @@ int gymhip_atari_stack_buffer(gymhip_atari* h, uint8_t** ring, int32_t* head) {
     return GYMHIP_OK;
 }
 
-int gymhip_atari_preprocess(gymhip_atari* h, const uint8_t* frames, uint8_t* out, void* stream) {
+int gymhip_atari_set_palette(gymhip_atari* h, const uint32_t* zrgb256) {
     if (int rc = check_atari(h)) return rc;
-    if (!frames || !out) return fail(GYMHIP_EINVAL, "frames/out is null");
-    return launch_preprocess(h, frames, out, (int64_t)h->cfg.dst_h * h->cfg.dst_w, 0, nullptr, false, (hipStream_t)stream);
+    if (!zrgb256) return fail(GYMHIP_EINVAL, "palette is null");
+    uint32_t packed[256];
+    for (int k = 0; k < 256; k++) {   // 0x00RRGGBB (ale_c_wrapper.cpp:35-38) -> bytes R, G, B in memory order
+        const uint32_t z = zrgb256[k];
+        packed[k] = ((z >> 16) & 0xffu) | (((z >> 8) & 0xffu) << 8) | ((z & 0xffu) << 16);
+    }
+    if (!h->lut) { void* p = nullptr; HIP_TRY(hipMalloc(&p, sizeof packed)); h->lut = (uint32_t*)p; }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h->lut, packed, sizeof packed, hipMemcpyHostToDevice));
+    return GYMHIP_OK;
 }
 
-int gymhip_atari_reset(gymhip_atari* h, const uint8_t* frames, void* stream) {
+static int preprocess_any(gymhip_atari* h, bool indexed, const uint8_t* frames, uint8_t* out, void* stream) {
+    if (int rc = check_atari(h)) return rc;
+    if (!frames || !out) return fail(GYMHIP_EINVAL, "frames/out is null");
+    return launch_preprocess(h, indexed, frames, out, (int64_t)h->cfg.dst_h * h->cfg.dst_w, 0, nullptr, false, (hipStream_t)stream);
+}
+
+static int reset_any(gymhip_atari* h, bool indexed, const uint8_t* frames, void* stream) {
     if (int rc = check_atari(h)) return rc;
     if (!frames) return fail(GYMHIP_EINVAL, "frames is null");
+    if (indexed && !h->lut) return fail(GYMHIP_ESTATE, "indexed frames need a colour table first (gymhip_atari_set_palette)");
     const int64_t plane = (int64_t)h->cfg.dst_h * h->cfg.dst_w;
     HIP_TRY(hipMemsetAsync(h->ring, 0, (size_t)h->cfg.n_envs * h->cfg.n_stack * plane, (hipStream_t)stream));   // stacked_observation.h:107
     h->head = h->cfg.n_stack - 1;
     h->did_reset = true;
-    return launch_preprocess(h, frames, h->ring, plane * h->cfg.n_stack, plane * h->head, nullptr, false, (hipStream_t)stream);
+    return launch_preprocess(h, indexed, frames, h->ring, plane * h->cfg.n_stack, plane * h->head, nullptr, false, (hipStream_t)stream);
 }
 
-int gymhip_atari_step(gymhip_atari* h, const uint8_t* frames, const uint8_t* done, void* stream) {
+static int step_any(gymhip_atari* h, bool indexed, const uint8_t* frames, const uint8_t* done, void* stream) {
     if (int rc = check_atari(h)) return rc;
     if (!frames) return fail(GYMHIP_EINVAL, "frames is null");
     if (!h->did_reset) return fail(GYMHIP_ESTATE, "atari step before reset");
+    if (indexed && !h->lut) return fail(GYMHIP_ESTATE, "indexed frames need a colour table first (gymhip_atari_set_palette)");
     const int64_t plane = (int64_t)h->cfg.dst_h * h->cfg.dst_w;
     h->head = (h->head + 1) % h->cfg.n_stack;   // ring advance == the reference's roll(-1) + write-last (stacked_observation.h:126-130, intended semantics)
-    return launch_preprocess(h, frames, h->ring, plane * h->cfg.n_stack, plane * h->head, done, true, (hipStream_t)stream);
+    return launch_preprocess(h, indexed, frames, h->ring, plane * h->cfg.n_stack, plane * h->head, done, true, (hipStream_t)stream);
 }
+
+int gymhip_atari_preprocess(gymhip_atari* h, const uint8_t* frames, uint8_t* out, void* stream) { return preprocess_any(h, false, frames, out, stream); }
+int gymhip_atari_reset(gymhip_atari* h, const uint8_t* frames, void* stream) { return reset_any(h, false, frames, stream); }
+int gymhip_atari_step(gymhip_atari* h, const uint8_t* frames, const uint8_t* done, void* stream) { return step_any(h, false, frames, done, stream); }
+int gymhip_atari_preprocess_indexed(gymhip_atari* h, const uint8_t* screens, uint8_t* out, void* stream) { return preprocess_any(h, true, screens, out, stream); }
+int gymhip_atari_reset_indexed(gymhip_atari* h, const uint8_t* screens, void* stream) { return reset_any(h, true, screens, stream); }
+int gymhip_atari_step_indexed(gymhip_atari* h, const uint8_t* screens, const uint8_t* done, void* stream) { return step_any(h, true, screens, done, stream); }
 
 int gymhip_atari_materialize_nhwc(gymhip_atari* h, uint8_t* out, void* stream) {
     if (int rc = check_atari(h)) return rc;

@@ -198,6 +198,17 @@ int gymhip_atari_stack_buffer(gymhip_atari* h, uint8_t** ring, int32_t* head);
 int gymhip_atari_preprocess(gymhip_atari* h, const uint8_t* frames, uint8_t* out, void* stream);
 int gymhip_atari_reset(gymhip_atari* h, const uint8_t* frames, void* stream);
 int gymhip_atari_step(gymhip_atari* h, const uint8_t* frames, const uint8_t* done, void* stream);
+/* The emulator's native screens instead of RGB frames.  AtariEnv::getObs colours ale->getScreen().getArray() (one palette
+ * index per pixel) on the host through a 256-entry 0x00RRGGBB table (getScreenRGB2, atari/ale_c_wrapper.cpp:28-41;
+ * the table is atari/atari_ntsc_rgb_palette.h) and hands RGB to the wrappers.  Here the host uploads the index screens
+ * — a third of the bytes over PCIe and out of HBM — and the kernel applies the same table before the max:
+ *   _set_palette: `zrgb256` = host array of 256 words 0x00RRGGBB (pass the reference's rgb_palette); call once.
+ *   _*_indexed:   as the three calls above with `screens` = device u8 [n_envs][2][src_h][src_w].
+ * Results are identical to colouring on the host and calling the RGB entry points. */
+int gymhip_atari_set_palette(gymhip_atari* h, const uint32_t* zrgb256);
+int gymhip_atari_preprocess_indexed(gymhip_atari* h, const uint8_t* screens, uint8_t* out, void* stream);
+int gymhip_atari_reset_indexed(gymhip_atari* h, const uint8_t* screens, void* stream);
+int gymhip_atari_step_indexed(gymhip_atari* h, const uint8_t* screens, const uint8_t* done, void* stream);
 /* The stacked observation as a contiguous tensor: channels-last u8 [n_envs][dst_h][dst_w][n_stack], oldest frame in
  * channel 0 (what VecFrameStack returns over WarpFrame's {84,84,1} space, stacked_observation.h:96-99,203-209). */
 int gymhip_atari_materialize_nhwc(gymhip_atari* h, uint8_t* out, void* stream);

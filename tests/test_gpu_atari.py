@@ -55,6 +55,53 @@ def test_preprocess_structured_and_random(oracle, gray_bits):
     assert (got[0] == 0).all() and (got[1] == 255).all() and (got[2] == 200).all()
 
 
+def synthetic_palette(seed):
+    """256 words 0x00RRGGBB in the shape of the emulator's NTSC table (atari_ntsc_rgb_palette.h): 128 colours on the even
+    indices, zeros on the odd ones; the colours themselves are seeded random (the kernel is table-agnostic)."""
+    rng = np.random.default_rng(seed)
+    pal = np.zeros(256, np.uint32)
+    pal[0::2] = rng.integers(0, 1 << 24, 128, dtype=np.uint32)
+    pal[0] = 0x000000; pal[14] = 0xECECEC                           # the table's first row ends: black and near-white
+    return pal
+
+
+def colour_on_host(screens, pal):
+    """getScreenRGB2 (ale_c_wrapper.cpp:28-41): index -> (R, G, B) bytes."""
+    z = pal[screens]
+    return np.stack([(z >> 16) & 255, (z >> 8) & 255, z & 255], axis=-1).astype(np.uint8)
+
+
+@pytest.mark.parametrize("gray_bits", [15, 14])
+def test_indexed_screens_equal_host_coloured_rgb(oracle, gray_bits):
+    """Palette-index screens + in-kernel colour table == colouring on the host and running the RGB path == the oracle."""
+    from gym_amd.atari import AtariPreprocessor
+    n = 24
+    pal = synthetic_palette(11)
+    rng = np.random.default_rng(5)
+    scr = (rng.integers(0, 128, (n, 2, H, W), dtype=np.uint8) * 2).astype(np.uint8)   # ALE emits even indices
+    scr[0] = 0; scr[1] = 14; scr[2, 0] = 0; scr[2, 1] = 14                              # constants, one frame dominating
+    scr[3] = rng.integers(0, 256, scr[3].shape, dtype=np.uint8)                          # odd indices too (table entry 0)
+    scr[4, :, 50:120, 30:100] = 14; scr[4, 1, 60:70] = 0                                 # blocks: large same-colour regions
+    rgb = colour_on_host(scr, pal)
+    pp = AtariPreprocessor(n, gray_bits=gray_bits)
+    with pytest.raises(Exception):
+        pp.preprocess(torch.from_numpy(scr).cuda())                                      # no colour table yet
+    pp.set_palette(pal)
+    got = pp.preprocess(torch.from_numpy(scr).cuda()).cpu().numpy()
+    via_rgb = pp.preprocess(torch.from_numpy(rgb).cuda()).cpu().numpy()
+    want = oracle.atari_preprocess(rgb, gray15=int(gray_bits == 15))
+    assert np.array_equal(got, via_rgb)
+    assert np.array_equal(got, want)
+    assert (got[0] == 0).all() and len(np.unique(got[1])) == 1
+    # the stack path: reset + steps on screens vs on host-coloured frames
+    pp2 = AtariPreprocessor(n, gray_bits=gray_bits)
+    pp.reset(torch.from_numpy(scr).cuda()); pp2.reset(torch.from_numpy(rgb).cuda())
+    for t in range(5):
+        s2 = np.roll(scr, t + 1, axis=2)
+        pp.step(torch.from_numpy(s2).cuda()); pp2.step(torch.from_numpy(colour_on_host(s2, pal)).cuda())
+    assert np.array_equal(pp.stacked_nhwc().cpu().numpy(), pp2.stacked_nhwc().cpu().numpy())
+
+
 def test_frame_stack_ring_matches_shift_semantics(oracle):
     """reset + 9 steps (> 2 ring revolutions for k=4): NHWC stack and the NCHW/255 float view vs the oracle."""
     from gym_amd.atari import AtariPreprocessor
