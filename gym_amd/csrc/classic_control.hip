@@ -660,6 +660,55 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
     }
 }
 
+// VecEnv::reset(int index) (sync_env.h:128-139) under VecNormalize::reset(int index) (vec_normalize.h:179-189): one env is
+// reset, its return lane cleared, and its observation normalised with the CURRENT statistics (no RMS update).  Monitor
+// allows early resets (monitor.h:49, allowEarlyResets): the unfinished episode is dropped without a record.
+template <int KIND, bool LOCKSTEP>
+__global__ void reset_index_kernel(const StepParams p, int64_t i, float* obs_norm, float clip_obs, float epsilon) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    constexpr int F = EnvTraits<KIND>::F;
+    using T = typename std::conditional<LOCKSTEP, double, float>::type;
+    const StepBuffers& b = p.buf;
+    const bool tape_mode = KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE;
+    uint32_t cursor = CounterWord<KIND>::cursor(b.counter[i]);
+    int64_t e = p.step_counter;
+    if (tape_mode) {
+        e = cursor;
+        if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
+        cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
+    }
+    T s[F];
+    reset_state<KIND, T>(p, i, e, s);
+    float o[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) o[f] = (float)s[f];
+    if constexpr (LOCKSTEP) store_state<F>(b, i, s, o, p.error_flag);
+    store_obs(b.obs, i, o);
+    b.counter[i] = CounterWord<KIND>::pack(0, cursor, false, false);
+    if (b.returns) b.returns[i] = 0.f;                                   // vec_normalize.h:182
+    if (obs_norm) {                                                      // normalizeObs<true> (vec_normalize.h:118-123)
+#pragma unroll
+        for (int f = 0; f < F; f++)
+            obs_norm[i * F + f] = fminf(fmaxf((o[f] - p.stats_cur[f]) / sqrtf(p.stats_cur[F + f] + epsilon), -clip_obs), clip_obs);
+    }
+}
+
+// Batch moments of caller rows x f32 [rows][width] for Updateable::update (vec_normalize.h:191-206): shifted sums into
+// partial columns col0 .. col0+width-1 (S1) and col0_sq .. (S2); every other column of the row is zeroed.
+__global__ __launch_bounds__(kBlock) void batch_moments_kernel(const float* __restrict__ x, int64_t rows, int width, const float* shift, int col0, int col0_sq,
+                                                               double* partials) {
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    float sh[4] = {0, 0, 0, 0};
+    for (int f = 0; f < width; f++) sh[f] = shift[f];
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (int64_t)gridDim.x * kBlock)
+        for (int f = 0; f < width; f++) { const double d = (double)x[r * width + f] - (double)sh[f]; s1[f] += d; s2[f] += d * d; }
+    double cols[kMaxCols];
+#pragma unroll
+    for (int c = 0; c < kMaxCols; c++) cols[c] = 0.0;
+    for (int f = 0; f < width; f++) { cols[col0 + f] = s1[f]; cols[col0_sq + f] = s2[f]; }
+    block_reduce_store<kMaxCols>(cols, partials + (int64_t)blockIdx.x * kMaxCols, false);
+}
+
 // K steps in one launch; state lives in registers between steps.
 template <int KIND, bool LOCKSTEP>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepParams p, const uint8_t* __restrict__ tape, int64_t K,
@@ -1244,6 +1293,63 @@ int gymhip_poll_error(gymhip_engine* h, int32_t* host_out, void* stream) {
     if (!host_out) return fail(GYMHIP_EINVAL, "host_out is null");
     HIP_TRY(hipMemcpyAsync(host_out, h->at<int32_t>(h->L.error_flag), 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return GYMHIP_OK;
+}
+
+int gymhip_reset_index(gymhip_engine* h, int64_t index, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (index < 0 || index >= h->cfg.n_envs) return fail(GYMHIP_EINVAL, "env index %lld out of range [0, %lld)", (long long)index, (long long)h->cfg.n_envs);
+    if (!h->did_reset) return fail(GYMHIP_ESTATE, "reset(index) before reset()");
+    if (h->pending_finish) return fail(GYMHIP_ESTATE, "previous *_begin has no matching *_finish");
+    const StepParams p = make_params(h);
+    float* on = (h->cfg.wrappers & GYMHIP_WRAP_NORM_OBS) ? h->at<float>(h->L.obs_norm) : nullptr;
+    const bool lock = h->cfg.precision == GYMHIP_PRECISION_LOCKSTEP_F64;
+    hipStream_t s = (hipStream_t)stream;
+    if (h->cfg.env_kind == KIND_CARTPOLE) {
+        if (lock) hipLaunchKernelGGL((reset_index_kernel<KIND_CARTPOLE, true>), dim3(1), dim3(64), 0, s, p, index, on, h->cfg.clip_obs, h->cfg.epsilon);
+        else hipLaunchKernelGGL((reset_index_kernel<KIND_CARTPOLE, false>), dim3(1), dim3(64), 0, s, p, index, on, h->cfg.clip_obs, h->cfg.epsilon);
+    } else {
+        if (lock) hipLaunchKernelGGL((reset_index_kernel<KIND_MOUNTAINCAR, true>), dim3(1), dim3(64), 0, s, p, index, on, h->cfg.clip_obs, h->cfg.epsilon);
+        else hipLaunchKernelGGL((reset_index_kernel<KIND_MOUNTAINCAR, false>), dim3(1), dim3(64), 0, s, p, index, on, h->cfg.clip_obs, h->cfg.epsilon);
+    }
+    HIP_TRY(hipGetLastError());
+    h->step_counter += 1;
+    return GYMHIP_OK;
+}
+
+int gymhip_update_norm_stats(gymhip_engine* h, const float* obs_rows, int64_t n_obs_rows, const float* reward_rows, int64_t n_reward_rows, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->norm) return fail(GYMHIP_EINVAL, "engine has no normaliser");
+    if (h->pending_finish) return fail(GYMHIP_ESTATE, "previous *_begin has no matching *_finish");
+    if ((obs_rows && n_obs_rows <= 0) || (reward_rows && n_reward_rows <= 0)) return fail(GYMHIP_EINVAL, "row counts must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    const int F = h->F;
+    // one pass per statistic: batch moments -> moments buffer -> RunningMeanStd::updateFromMoment (no normalisation: n = 0 rows)
+    auto pass = [&](const float* x, int64_t rows, int width, int stat_off, int col0, int col0_sq, bool is_obs) -> int {
+        int64_t g64 = (rows + kBlock - 1) / kBlock;
+        const int g = (int)(g64 < kDefaultGrid ? g64 : kDefaultGrid);
+        hipLaunchKernelGGL(batch_moments_kernel, dim3(g), dim3(kBlock), 0, s, x, rows, width, h->stats_slot_ptr(h->stats_slot) + stat_off, col0, col0_sq,
+                           h->at<double>(h->L.partials));
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kReduceThreads), 0, s, h->at<double>(h->L.partials), g, 2 * F + 5, (double)rows,
+                           h->at<double>(h->L.moments));
+        NormParams q{};
+        q.n = 0;
+        q.stats_cur = h->stats_slot_ptr(h->stats_slot);
+        q.stats_next = h->stats_slot_ptr(h->stats_slot ^ 1);
+        q.stats_public = h->stats_slot_ptr(2);
+        q.moments = h->at<double>(h->L.moments);
+        q.clip_obs = h->cfg.clip_obs; q.clip_reward = h->cfg.clip_reward; q.epsilon = h->cfg.epsilon;
+        q.update_obs = is_obs; q.update_ret = !is_obs;
+        if (F == 4) hipLaunchKernelGGL(normalize_kernel<4>, dim3(1), dim3(kBlock), 0, s, q);
+        else hipLaunchKernelGGL(normalize_kernel<2>, dim3(1), dim3(kBlock), 0, s, q);
+        h->stats_slot ^= 1;
+        HIP_TRY(hipGetLastError());
+        return GYMHIP_OK;
+    };
+    if (obs_rows && (h->cfg.wrappers & GYMHIP_WRAP_NORM_OBS))
+        if (int rc = pass(obs_rows, n_obs_rows, F, 0, 0, F, true)) return rc;                       // updateObservation (vec_normalize.h:199-201)
+    if (reward_rows && (h->cfg.wrappers & GYMHIP_WRAP_NORM_REWARD))
+        if (int rc = pass(reward_rows, n_reward_rows, 1, 2 * F + 1, 2 * F, 2 * F + 1, false)) return rc;   // m_RetRMS->update (vec_normalize.h:203-205)
     return GYMHIP_OK;
 }
 

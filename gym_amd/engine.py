@@ -198,6 +198,23 @@ class Engine:
         L.check(self.lib.gymhip_poll_error(self.h, C.byref(v), self._stream()), "gymhip_poll_error")
         return v.value
 
+    def reset_index(self, index: int):
+        """VecEnv::reset(int index) (+ VecNormalize::reset(int index)): results are row `index` of obs / obs_norm."""
+        L.check(self.lib.gymhip_reset_index(self.h, int(index), self._stream()), "gymhip_reset_index")
+
+    def update_norm_stats(self, obs_rows: torch.Tensor | None = None, reward_rows: torch.Tensor | None = None):
+        """Updateable::update (vec_normalize.h:191-206): push rollout rows into the running statistics."""
+        def prep(t, width):
+            if t is None:
+                return None, 0
+            t = t.to(self.device, torch.float32).reshape(-1, width).contiguous()
+            return t, t.shape[0]
+        o, no = prep(obs_rows, self.F)
+        r, nr = prep(reward_rows, 1)
+        L.check(self.lib.gymhip_update_norm_stats(self.h, C.c_void_p(o.data_ptr()) if o is not None else None, no,
+                                                  C.c_void_p(r.data_ptr()) if r is not None else None, nr, self._stream()),
+                "gymhip_update_norm_stats")
+
     def get_norm_stats(self) -> np.ndarray:
         out = np.zeros(2 * self.F + 4, np.float32)
         L.check(self.lib.gymhip_get_norm_stats(self.h, out.ctypes.data_as(C.c_void_p), self._stream()), "gymhip_get_norm_stats")

@@ -99,11 +99,61 @@ public:
         return out;
     }
 
+    // VecNormalize::save / load (vec_normalize.h:79-108): `returns.pt` and `observation.pt` under `dir`, each the archive
+    // RunningMeanStdImpl::save writes — three non-buffer tensors "mean", "m_Var", "m_Count" (running_mean_std.h:28-40) —
+    // so files move freely between this class and the reference's VecNormalize.  Synchronise the stream.
+    void save(std::string const& dir) {
+        if (!hasNorm() || !ensure()) return;
+        std::vector<float> s(16);
+        if (!ok(gymhip_get_norm_stats(h, s.data(), opt.stream), "gymhip_get_norm_stats")) return;
+        const int64_t F = buf.obs_dim;
+        auto put = [&](const char* file, torch::Tensor mean, torch::Tensor var, float count) {
+            torch::serialize::OutputArchive ar;
+            ar.write("mean", mean); ar.write("m_Var", var); ar.write("m_Count", torch::tensor(count, torch::kFloat32));
+            ar.save_to(dir + "/" + file);
+        };
+        if (opt.norm_reward) put("returns.pt", torch::tensor(s[2 * F + 1], torch::kFloat32), torch::tensor(s[2 * F + 2], torch::kFloat32), s[2 * F + 3]);
+        if (opt.norm_obs) put("observation.pt", torch::from_blob(s.data(), {F}, torch::kFloat32).clone(), torch::from_blob(s.data() + F, {F}, torch::kFloat32).clone(), s[2 * F]);
+    }
+    void load(std::string const& dir) {
+        if (!hasNorm() || !ensure()) return;
+        std::vector<float> s(16);
+        if (!ok(gymhip_get_norm_stats(h, s.data(), opt.stream), "gymhip_get_norm_stats")) return;
+        const int64_t F = buf.obs_dim;
+        auto get = [&](const char* file, float* mean, float* var, float* count, int64_t numel) {
+            torch::serialize::InputArchive ar;
+            ar.load_from(dir + "/" + file);
+            torch::Tensor m, v, c;
+            ar.read("mean", m); ar.read("m_Var", v); ar.read("m_Count", c);
+            if (m.numel() != numel || v.numel() != numel) throw std::runtime_error(std::string(file) + ": statistics of a different feature shape");
+            m = m.to(torch::kCPU, torch::kFloat32).contiguous().reshape({-1}); v = v.to(torch::kCPU, torch::kFloat32).contiguous().reshape({-1});
+            std::copy_n(m.data_ptr<float>(), numel, mean); std::copy_n(v.data_ptr<float>(), numel, var);
+            *count = c.item<float>();
+        };
+        if (opt.norm_reward) get("returns.pt", &s[2 * F + 1], &s[2 * F + 2], &s[2 * F + 3], 1);
+        if (opt.norm_obs) get("observation.pt", &s[0], &s[F], &s[2 * F], F);
+        ok(gymhip_set_norm_stats(h, s.data(), opt.stream), "gymhip_set_norm_stats");
+    }
+
     torch::Tensor oldObs() const { return obs; }                         // vec_normalize.h:94
     torch::Tensor normStats() const { return norm_stats; }               // [2F+4]: obs mean, var, count, ret mean, var, count
     gymhip_engine* handle() const { return h; }
 
-    torch::Tensor reset(int) override { throw std::runtime_error("HipVecEnv::reset(int index): not implemented (per-index paths)"); }
+    // sync_env.h:128-139 (+ vec_normalize.h:179-189 with the normaliser fused in): one env is reset; returns its row
+    torch::Tensor reset(int index) override {
+        if (!h) throw std::runtime_error("HipVecEnv::reset(int index) before reset()");
+        if (gymhip_reset_index(h, index, opt.stream) != GYMHIP_OK) throw std::runtime_error(gymhip_last_error());
+        return (opt.norm_obs ? obs_norm : obs)[index];
+    }
+    // Updateable::update (vec_normalize.h:191-206): state [T][N][F] and reward, any device; rows are pushed into the statistics
+    void update(torch::Tensor const& state, torch::Tensor const& reward) {
+        if (!hasNorm() || !ensure()) return;
+        auto dev = torch::Device(torch::kCUDA, opt.device);
+        torch::Tensor s = state.defined() ? state.to(dev, torch::kFloat32).reshape({-1, (int64_t)buf.obs_dim}).contiguous() : torch::Tensor();
+        torch::Tensor r = reward.defined() ? reward.to(dev, torch::kFloat32).reshape({-1}).contiguous() : torch::Tensor();
+        ok(gymhip_update_norm_stats(h, s.defined() ? s.data_ptr<float>() : nullptr, s.defined() ? s.size(0) : 0,
+                                    r.defined() ? r.data_ptr<float>() : nullptr, r.defined() ? r.size(0) : 0, opt.stream), "gymhip_update_norm_stats");
+    }
     StepT step(int, torch::Tensor const&) noexcept override { return {}; }   // the reference's own stub returns buffered values (sync_env.h:141-157)
     void render() const override {}
 

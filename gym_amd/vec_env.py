@@ -213,7 +213,14 @@ class HipVecEnv(VecEnv):
 
     def reset(self, index=None):
         if index is not None:
-            raise NotImplementedError("reset(int index): per-index paths are a 'next' row (SURVEY.md §8f.2)")
+            # sync_env.h:128-139 (+ vec_normalize.h:179-189 when the normaliser is fused in): one env, returns its row
+            if self.engine is None:
+                raise RuntimeError("reset(index) before reset()")
+            if not 0 <= int(index) < self.numEnvs:
+                raise IndexError(f"env index {index} out of range [0, {self.numEnvs})")
+            self.engine.reset_index(int(index))
+            e = self.engine
+            return (e.obs_norm if (self._norm and self._norm["norm_obs"]) else e.obs)[int(index)]
         self._ensure_engine()
         e = self.engine
         e.reset_begin()
@@ -289,6 +296,12 @@ class VecNormalize(VecEnvWrapper):
         """vec_normalize.h:94: the un-normalised observations of the last reset/step."""
         return self.venv.engine.obs
 
+    def update(self, state: torch.Tensor | None, reward: torch.Tensor | None):
+        """Updateable::update (vec_normalize.h:191-206): a learner pushes rollout tensors — state [T, N, F] (flattened over
+        the first two dims, :197) and reward (reshaped to [-1, 1], :204) — into the running statistics."""
+        self.venv._ensure_engine()
+        self.venv.engine.update_norm_stats(state, reward)
+
     def get(self):
         """vec_normalize.h:75-77: (obs RMS, return RMS) as dicts of mean / m_Var / m_Count (running_mean_std.h:17-19)."""
         s = self.venv.engine.get_norm_stats()
@@ -297,26 +310,30 @@ class VecNormalize(VecEnvWrapper):
                 dict(mean=float(s[2 * F + 1]), m_Var=float(s[2 * F + 2]), m_Count=float(s[2 * F + 3])))
 
     def save(self, path):
-        """vec_normalize.h:79-92: returns.pt + observation.pt, each {mean, m_Var, m_Count} (running_mean_std.h:28-33)."""
+        """vec_normalize.h:79-92: returns.pt + observation.pt in the reference's own archive format (gym_amd/checkpoint.py)."""
+        from .checkpoint import save_running_mean_std
         os.makedirs(path, exist_ok=True)
         obs, ret = self.get()
         if self.venv._norm["norm_reward"]:
-            torch.save({k: torch.as_tensor(v, dtype=torch.float32) for k, v in ret.items()}, os.path.join(path, "returns.pt"))
+            save_running_mean_std(os.path.join(path, "returns.pt"), np.float32(ret["mean"]), np.float32(ret["m_Var"]), ret["m_Count"])
         if self.venv._norm["norm_obs"]:
-            torch.save({k: torch.as_tensor(v, dtype=torch.float32) for k, v in obs.items()}, os.path.join(path, "observation.pt"))
+            save_running_mean_std(os.path.join(path, "observation.pt"), obs["mean"], obs["m_Var"], obs["m_Count"])
 
     def load(self, path):
         """vec_normalize.h:96-108."""
+        from .checkpoint import load_running_mean_std
         self.venv._ensure_engine()
         e = self.venv.engine
         s = e.get_norm_stats()
         F = e.F
         if self.venv._norm["norm_reward"]:
-            r = torch.load(os.path.join(path, "returns.pt"), weights_only=True)
-            s[2 * F + 1], s[2 * F + 2], s[2 * F + 3] = float(r["mean"]), float(r["m_Var"]), float(r["m_Count"])
+            mean, var, cnt = load_running_mean_std(os.path.join(path, "returns.pt"))
+            s[2 * F + 1], s[2 * F + 2], s[2 * F + 3] = float(mean), float(var), cnt
         if self.venv._norm["norm_obs"]:
-            o = torch.load(os.path.join(path, "observation.pt"), weights_only=True)
-            s[:F], s[F:2 * F], s[2 * F] = o["mean"].numpy(), o["m_Var"].numpy(), float(o["m_Count"])
+            mean, var, cnt = load_running_mean_std(os.path.join(path, "observation.pt"))
+            if mean.shape != (F,):
+                raise ValueError(f"observation.pt holds statistics of shape {mean.shape}, this env has {F} features")
+            s[:F], s[F:2 * F], s[2 * F] = mean, var, cnt
         e.set_norm_stats(s)
 
 

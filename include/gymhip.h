@@ -160,6 +160,20 @@ int gymhip_episode_stats(gymhip_engine* h, double* host_out, void* stream);
  * range (non-finite, or nonzero below 2^-126 — the dynamics never produce either). */
 int gymhip_poll_error(gymhip_engine* h, int32_t* host_out, void* stream);
 
+/* VecEnv::reset(int index) (base.h:54; sync_env.h:128-139) under VecNormalize::reset(int index) (vec_normalize.h:179-189):
+ * env `index` alone is reset (it consumes its next reset-tape row / a fresh stateless draw), its return lane is zeroed,
+ * and obs_norm[index] is normalised with the current statistics, which are NOT updated.  The env's unfinished episode is
+ * dropped without an episode record (Monitor's allowEarlyResets, monitor.h:49).  The per-index step(index, action) of
+ * the reference is a stub that returns buffered values (sync_env.h:141-157): read the buffers. */
+int gymhip_reset_index(gymhip_engine* h, int64_t index, void* stream);
+
+/* Updateable::update / VecNormalize::update (vec_normalize.h:191-206): a learner pushes rollout data into the running
+ * statistics.  obs_rows: device f32 [n_obs_rows][F] (the reference flattens [T][N][F], :197) -> obsRMS.update;
+ * reward_rows: device f32 [n_reward_rows] (reshape({-1,1}), :204) -> retRMS.update.  Either pointer may be NULL.  Every
+ * rank must push the same rows (the statistics are replicated). */
+int gymhip_update_norm_stats(gymhip_engine* h, const float* obs_rows, int64_t n_obs_rows, const float* reward_rows, int64_t n_reward_rows,
+                             void* stream);
+
 /* VecNormalize::save/load state (vec_normalize.h:79-108; running_mean_std.h:28-40) as 2F+4 floats, host side. */
 int gymhip_get_norm_stats(gymhip_engine* h, float* host_out, void* stream);
 int gymhip_set_norm_stats(gymhip_engine* h, const float* host_in, void* stream);

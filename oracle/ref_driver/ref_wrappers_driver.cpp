@@ -5,6 +5,8 @@
 // tests/golden/ref_*.npz so the pin also travels to the GPU box.
 //
 // usage: ref_wrappers_driver wrappers <in> <out>   |   ref_wrappers_driver rms <in> <out>
+//        ref_wrappers_driver ckpt_save <in.bin> <out.pt>   the reference's torch::save(RunningMeanStd) after updates (vec_normalize.h:79-92)
+//        ref_wrappers_driver ckpt_load <in.pt> <out.bin>   the reference's torch::load(RunningMeanStd) (vec_normalize.h:96-108)
 #include "wrappers/time_limit.h"
 #include "wrappers/clip_reward.h"
 #include "wrappers/monitor.h"
@@ -77,11 +79,47 @@ int run_rms(const char* in, const char* out) {
     return 0;
 }
 
+// in: int64 F (0 = scalar shape {}, as the return statistics, vec_normalize.h:57), int64 n, float x[n][max(F,1)].
+// out.pt: torch::save of the reference module after one update(x); <out.pt>.bin: mean[F'], var[F'], count as floats.
+int run_ckpt_save(const char* in, const char* out) {
+    FILE* f = fopen(in, "rb"); if (!f) return 2;
+    int64_t F, n;
+    if (!rd(f, &F, 1) || !rd(f, &n, 1)) return 2;
+    const int64_t W = F > 0 ? F : 1;
+    std::vector<float> x(n * W); if (!rd(f, x.data(), n * W)) return 2;
+    fclose(f);
+    RunningMeanStd rms(F > 0 ? std::vector<int64_t>{F} : std::vector<int64_t>{});
+    auto t = torch::from_blob(x.data(), F > 0 ? std::vector<int64_t>{n, F} : std::vector<int64_t>{n}, torch::kFloat32).clone();
+    rms->update(t);
+    torch::save(rms, std::string(out));
+    FILE* o = fopen((std::string(out) + ".bin").c_str(), "wb"); if (!o) return 2;
+    auto mean = rms->mean<false>().contiguous().reshape({-1}), var = rms->var<false>().contiguous().reshape({-1}); float cnt = rms->count().item<float>();
+    fwrite(mean.data_ptr<float>(), 4, W, o); fwrite(var.data_ptr<float>(), 4, W, o); fwrite(&cnt, 4, 1, o);
+    fclose(o);
+    return 0;
+}
+
+// out.bin: int64 numel, then mean[numel], var[numel], count as floats, read back through the reference's load().
+int run_ckpt_load(const char* in, const char* out) {
+    RunningMeanStd rms;                       // default-constructed: load() assigns the three tensors (running_mean_std.h:35-40)
+    torch::load(rms, std::string(in));
+    auto mean = rms->mean<false>().contiguous().reshape({-1}), var = rms->var<false>().contiguous().reshape({-1}); float cnt = rms->count().item<float>();
+    if (mean.scalar_type() != torch::kFloat32 || var.scalar_type() != torch::kFloat32) return 3;
+    FILE* o = fopen(out, "wb"); if (!o) return 2;
+    int64_t numel = mean.numel();
+    fwrite(&numel, 8, 1, o);
+    fwrite(mean.data_ptr<float>(), 4, numel, o); fwrite(var.data_ptr<float>(), 4, numel, o); fwrite(&cnt, 4, 1, o);
+    fclose(o);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
-    if (argc != 4) { fprintf(stderr, "usage: %s wrappers|rms <in> <out>\n", argv[0]); return 1; }
+    if (argc != 4) { fprintf(stderr, "usage: %s wrappers|rms|ckpt_save|ckpt_load <in> <out>\n", argv[0]); return 1; }
     if (!strcmp(argv[1], "wrappers")) return run_wrappers(argv[2], argv[3]);
     if (!strcmp(argv[1], "rms")) return run_rms(argv[2], argv[3]);
+    if (!strcmp(argv[1], "ckpt_save")) return run_ckpt_save(argv[2], argv[3]);
+    if (!strcmp(argv[1], "ckpt_load")) return run_ckpt_load(argv[2], argv[3]);
     return 1;
 }

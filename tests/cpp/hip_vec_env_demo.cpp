@@ -1,7 +1,7 @@
 // A training-loop-shaped driver of gym::HipVecEnv, modelled on the reference's own smoke test
 // (test/classic_control.cpp:69-99, p_test_run): build the vec env, reset, check shapes, step with a tensor of actions.
 // Prints one line per step so tests/test_cpp_host.py can compare against the CPU oracle.
-//   usage: hip_vec_env_demo <cartpole|mountaincar> <n_envs> <steps> <norm 0|1>
+//   usage: hip_vec_env_demo <cartpole|mountaincar> <n_envs> <steps> <norm 0|1> [checkpoint_dir]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -9,7 +9,7 @@
 #include "gym/hip_vec_env.h"
 
 int main(int argc, char** argv) {
-    if (argc != 5) { std::fprintf(stderr, "usage: %s cartpole|mountaincar n_envs steps norm\n", argv[0]); return 2; }
+    if (argc != 5 && argc != 6) { std::fprintf(stderr, "usage: %s cartpole|mountaincar n_envs steps norm\n", argv[0]); return 2; }
     const bool cart = !std::strcmp(argv[1], "cartpole");
     const int64_t n = std::atoll(argv[2]);
     const int steps = std::atoi(argv[3]);
@@ -43,6 +43,16 @@ int main(int argc, char** argv) {
             for (auto& m : infos) if (m.count("episode")) { with_ep++; len_sum += std::any_cast<gym::Result>(m["episode"]).l; }
             std::printf("infos %d %.1f\n", with_ep, len_sum);
         }
+    }
+    if (argc == 6 && norm) {
+        // VecNormalize::save, then ::load into a second, evaluation-mode env (vec_normalize.h:79-108)
+        auto* trained = static_cast<gym::HipVecEnv*>(env.get());
+        trained->save(argv[5]);
+        o.norm_obs = o.norm_reward = true; o.training = false;
+        auto eval_env = std::make_unique<gym::HipVecEnv>(o);
+        eval_env->load(argv[5]);
+        auto a = trained->normStats().cpu(), b = eval_env->normStats().cpu();
+        std::printf("ckpt %d\n", (int)torch::equal(a, b));
     }
     return 0;
 }

@@ -57,7 +57,40 @@ def run_rms(batches, F):
         return np.fromfile(fout, np.float32).reshape(len(batches), 4 * F + 1)
 
 
+def ckpt_batch(seed, F, n=37):
+    return np.random.default_rng(seed).standard_normal((n, max(F, 1))).astype(np.float32)
+
+
+def run_ckpt_save(x, F, out_pt):
+    """The reference's torch::save(RunningMeanStd) after one update(x) -> file out_pt; returns (mean, var, count) it held."""
+    with tempfile.TemporaryDirectory() as d:
+        fin = os.path.join(d, "in")
+        with open(fin, "wb") as f:
+            f.write(np.array([F, x.shape[0]], np.int64).tobytes()); f.write(np.ascontiguousarray(x).tobytes())
+        subprocess.run([DRIVER, "ckpt_save", fin, out_pt], check=True, capture_output=True)
+    v = np.fromfile(out_pt + ".bin", np.float32)
+    os.remove(out_pt + ".bin")
+    W = max(F, 1)
+    return v[:W], v[W:2 * W], float(v[2 * W])
+
+
+def run_ckpt_load(in_pt):
+    """The reference's torch::load(RunningMeanStd) of a file -> (mean, var, count) flattened."""
+    with tempfile.TemporaryDirectory() as d:
+        fout = os.path.join(d, "out")
+        subprocess.run([DRIVER, "ckpt_load", in_pt, fout], check=True, capture_output=True)
+        raw = open(fout, "rb").read()
+    n = int(np.frombuffer(raw[:8], np.int64)[0])
+    v = np.frombuffer(raw[8:], np.float32)
+    return v[:n], v[n:2 * n], float(v[2 * n])
+
+
 def main():
+    # checkpoints written by the reference's own save(): observation statistics (F = 4) and the scalar return statistics
+    for name, F, seed in (("observation", 4, 21), ("returns", 0, 22)):
+        pt = os.path.join(OUT, f"ref_rms_checkpoint_{name}.pt")
+        mean, var, cnt = run_ckpt_save(ckpt_batch(seed, F), F, pt)
+        np.savez(os.path.join(OUT, f"ref_rms_checkpoint_{name}.npz"), F=F, batch_seed=seed, mean=mean, var=var, count=np.float32(cnt))
     rew, done = wrapper_script(11, 997)
     rec = run_wrappers(rew, done, 13, 4000)
     np.savez_compressed(os.path.join(OUT, "ref_wrappers.npz"), script_seed=11, script_len=997, max_steps=13, steps=4000,

@@ -18,15 +18,15 @@ def test_cpp_mirror_compiles_and_links():
     assert os.path.exists(BIN)
 
 
-def _run(env, n, steps, norm):
-    r = subprocess.run([BIN, env, str(n), str(steps), str(int(norm))], capture_output=True, text=True, timeout=240)
+def _run(env, n, steps, norm, ckpt_dir=None):
+    r = subprocess.run([BIN, env, str(n), str(steps), str(int(norm))] + ([str(ckpt_dir)] if ckpt_dir else []), capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     return [l.split() for l in r.stdout.strip().splitlines()]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env,norm", [("cartpole", False), ("mountaincar", True)])
-def test_cpp_training_loop_matches_oracle(oracle, env, norm):
+def test_cpp_training_loop_matches_oracle(oracle, env, norm, tmp_path):
     assert os.path.exists(BIN), "build tests/cpp first (python -c 'import __graft_entry__ as g; g.build()')"
     n, steps = 2048, 260
     cart = env == "cartpole"
@@ -35,7 +35,12 @@ def test_cpp_training_loop_matches_oracle(oracle, env, norm):
     v.seed(7)
     if norm:
         v.attach_norm()
-    lines = _run(env, n, steps, norm)
+    lines = _run(env, n, steps, norm, tmp_path if norm else None)
+    if norm:
+        # the C++ mirror's save(): files in the reference's archive format, reloaded by its own load() and readable here
+        from gym_amd.checkpoint import load_running_mean_std
+        assert lines[-1] == ["ckpt", "1"]
+        lines = lines[:-1]
     obs0 = v.norm_reset()[0] if norm else v.reset()
     assert lines[0][0] == "reset" and np.isclose(float(lines[0][1]), obs0.astype(np.float64).sum(), rtol=1e-6, atol=1e-3)
     idx = np.arange(n, dtype=np.int64)
@@ -49,3 +54,11 @@ def test_cpp_training_loop_matches_oracle(oracle, env, norm):
         assert np.isclose(float(rew_sum), r["reward"].astype(np.float64).sum(), rtol=1e-5, atol=1e-3), t
     d = r["done"] != 0
     assert lines[-1][0] == "infos" and int(lines[-1][1]) == int(d.sum()) and float(lines[-1][2]) == float(r["ep_l"][d].sum())
+    if norm:
+        st = v.norm_stats()
+        F = 2
+        om, ov_, oc = load_running_mean_std(str(tmp_path / "observation.pt"))
+        rm, rv, rc = load_running_mean_std(str(tmp_path / "returns.pt"))
+        assert om.shape == (F,) and rm.shape == ()
+        assert np.allclose(om, st[:F], rtol=1e-5, atol=1e-7) and np.allclose(ov_, st[F:2 * F], rtol=1e-5) and oc == st[2 * F]
+        assert np.isclose(float(rm), st[2 * F + 1], rtol=1e-5) and np.isclose(float(rv), st[2 * F + 2], rtol=1e-5) and rc == st[2 * F + 3]

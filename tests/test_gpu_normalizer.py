@@ -172,3 +172,70 @@ def test_norm_stats_save_load_roundtrip():
     mean, var = saved[:2], saved[2:4]
     want = np.clip((b.obs.cpu().numpy() - mean) / np.sqrt(var + np.float32(1e-8)), -10, 10)
     assert np.allclose(b.obs_norm.cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+
+
+def test_reset_index_resets_one_env_without_touching_the_statistics(oracle):
+    """VecEnv::reset(int index) under VecNormalize (sync_env.h:128-139, vec_normalize.h:179-189): env `index` takes its next
+    reset-tape row, its return lane is zeroed, obs_norm[index] uses the CURRENT statistics, nothing else changes."""
+    from gym_amd import _lib as L
+    n, seed = 512, 3
+    eng = _engine(L.ENV_CARTPOLE, n, L.WRAP_TIME_LIMIT | L.WRAP_MONITOR | _norm_flags(), 500)
+    tape = oracle.cartpole_reset_tape(seed, n, 16)
+    eng.upload_reset_tape(tape)
+    eng.reset()
+    acts = torch.from_numpy(splitmix_actions(9, 30, n, 2)).cuda()
+    for t in range(30):
+        eng.step(acts[t])
+    before = {k: getattr(eng, k).clone() for k in ("obs", "obs_norm", "returns", "counter", "reward", "done")}
+    state_before = eng.state_f64().clone()
+    stats = eng.get_norm_stats()
+    cur = eng.counters()
+    for index in (0, 77, n - 1):
+        cursor = int(cur["cursor"][index])
+        eng.reset_index(index)
+        row = tape[cursor, index]
+        assert np.array_equal(eng.obs[index].cpu().numpy(), row)
+        assert np.array_equal(eng.state_f64()[index].cpu().numpy(), row.astype(np.float64))       # floats widened (cartpole.cpp:23-26)
+        want = np.clip((row - stats[:4]) / np.sqrt(stats[4:8] + np.float32(1e-8)), -10, 10).astype(np.float32)
+        assert np.allclose(eng.obs_norm[index].cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+        assert float(eng.returns[index]) == 0.0
+        after = eng.counters()
+        assert int(after["elapsed"][index]) == 0 and int(after["cursor"][index]) == cursor + 1
+    assert np.array_equal(eng.get_norm_stats(), stats)                                              # no RMS update
+    keep = np.ones(n, bool); keep[[0, 77, n - 1]] = False
+    for k in ("obs", "obs_norm", "returns", "counter"):
+        assert torch.equal(getattr(eng, k)[torch.from_numpy(keep).cuda()], before[k][torch.from_numpy(keep).cuda()]), k
+    assert torch.equal(eng.reward, before["reward"]) and torch.equal(eng.done, before["done"])
+    assert torch.equal(eng.state_f64()[torch.from_numpy(keep).cuda()], state_before[torch.from_numpy(keep).cuda()])
+    with pytest.raises(Exception):
+        eng.reset_index(n)
+    eng.step(acts[0])                                                                               # the engine keeps stepping
+    assert eng.poll_error() == 0
+
+
+def test_update_pushes_rollout_rows_into_the_statistics(oracle):
+    """Updateable::update (vec_normalize.h:191-206) == RunningMeanStd::update on the flattened rows
+    (running_mean_std.h:42-66), checked against the oracle's RunningMeanStd (itself pinned to the reference's)."""
+    from gym_amd import _lib as L
+    n, F = 256, 2
+    eng = _engine(L.ENV_MOUNTAINCAR, n, L.WRAP_TIME_LIMIT | L.WRAP_MONITOR | _norm_flags(), 200)
+    eng.reset()
+    st = eng.get_norm_stats()
+    obs_st = np.concatenate([st[:F], st[F:2 * F], st[2 * F:2 * F + 1]]).astype(np.float32)
+    ret_st = st[2 * F + 1:2 * F + 4].astype(np.float32).copy()
+    rng = np.random.default_rng(4)
+    for k in range(5):
+        T = int(rng.integers(1, 40))
+        state = (rng.standard_normal((T, n, F)) * [0.3, 0.02] + [-0.5, 0.0]).astype(np.float32)
+        reward = rng.standard_normal((T, n)).astype(np.float32) * 3
+        eng.update_norm_stats(torch.from_numpy(state).cuda(), torch.from_numpy(reward).cuda() if k % 2 == 0 else None)
+        bm, bv = oracle.rms_batch_moments(state.reshape(-1, F))
+        oracle.rms_update_from_moments(obs_st, bm, bv, T * n)
+        if k % 2 == 0:
+            bm, bv = oracle.rms_batch_moments(reward.reshape(-1, 1))
+            oracle.rms_update_from_moments(ret_st, bm, bv, T * n)
+        got = eng.get_norm_stats()
+        _check_stats(got, np.concatenate([obs_st, ret_st]), F, f"update {k}")
+        assert got[2 * F] == obs_st[2 * F] and got[2 * F + 3] == ret_st[2]                          # counts are exact
+    eng.step(torch.zeros(n, dtype=torch.int32, device="cuda"))                                      # and the engine steps on
+    assert np.array_equal(eng.norm_stats.cpu().numpy(), eng.get_norm_stats())

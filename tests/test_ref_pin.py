@@ -73,3 +73,29 @@ def test_oracle_vs_live_reference_driver(oracle):
     for seed in (8, 9):
         b = R.rms_batches(seed, 12, 2)
         check_rms(oracle, R.run_rms(b, 2), b, 2)
+
+
+def test_checkpoint_files_written_by_the_reference_load_here():
+    """(f2) VecNormalize::save format: files produced by the reference's torch::save(RunningMeanStd) (frozen under
+    tests/golden/) read back bit-exactly through gym_amd.checkpoint."""
+    from gym_amd.checkpoint import load_running_mean_std
+    for name in ("observation", "returns"):
+        g = np.load(os.path.join(G, f"ref_rms_checkpoint_{name}.npz"))
+        mean, var, cnt = load_running_mean_std(os.path.join(G, f"ref_rms_checkpoint_{name}.pt"))
+        assert mean.shape == ((int(g["F"]),) if int(g["F"]) else ())
+        assert np.array_equal(mean.reshape(-1), g["mean"]) and np.array_equal(var.reshape(-1), g["var"]) and np.float32(cnt) == g["count"]
+
+
+@pytest.mark.skipif(not HAVE_DRIVER, reason="oracle/_ref not built (needs /root/reference; build container only)")
+def test_checkpoint_round_trip_with_live_reference_code(tmp_path):
+    """Both directions against the reference's own save()/load() (running_mean_std.h:28-40)."""
+    from gym_amd.checkpoint import load_running_mean_std, save_running_mean_std
+    for F, seed in ((4, 1), (2, 2), (0, 3)):
+        pt = str(tmp_path / f"ref_{F}.pt")
+        ref = R.run_ckpt_save(R.ckpt_batch(seed, F), F, pt)
+        got = load_running_mean_std(pt)
+        assert np.array_equal(got[0].reshape(-1), ref[0]) and np.array_equal(got[1].reshape(-1), ref[1]) and np.float32(got[2]) == np.float32(ref[2])
+        ours = str(tmp_path / f"ours_{F}.pt")
+        save_running_mean_std(ours, got[0], got[1], got[2])
+        back = R.run_ckpt_load(ours)
+        assert np.array_equal(back[0], ref[0]) and np.array_equal(back[1], ref[1]) and np.float32(back[2]) == np.float32(ref[2])
