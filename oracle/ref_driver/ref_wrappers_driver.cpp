@@ -5,6 +5,7 @@
 // tests/golden/ref_*.npz so the pin also travels to the GPU box.
 //
 // usage: ref_wrappers_driver wrappers <in> <out>   |   ref_wrappers_driver rms <in> <out>
+//        ref_wrappers_driver csv <in> <out.csv>            the reference's Monitor with a ResultWriter file (monitor.h:20-35,44-50,93-94)
 //        ref_wrappers_driver ckpt_save <in.bin> <out.pt>   the reference's torch::save(RunningMeanStd) after updates (vec_normalize.h:79-92)
 //        ref_wrappers_driver ckpt_load <in.pt> <out.bin>   the reference's torch::load(RunningMeanStd) (vec_normalize.h:96-108)
 #include "wrappers/time_limit.h"
@@ -79,6 +80,25 @@ int run_rms(const char* in, const char* out) {
     return 0;
 }
 
+// Same scripted env as run_wrappers, Monitor constructed with id "env7" and a file name: the CSV the reference writes.
+int run_csv(const char* in, const char* out) {
+    FILE* f = fopen(in, "rb"); if (!f) return 2;
+    int64_t L, max_steps, steps, flags;
+    if (!rd(f, &L, 1) || !rd(f, &max_steps, 1) || !rd(f, &steps, 1) || !rd(f, &flags, 1)) return 2;
+    std::vector<float> rew(L); std::vector<uint8_t> dn(L);
+    if (!rd(f, rew.data(), L) || !rd(f, dn.data(), L)) return 2;
+    fclose(f);
+    using TL = gym::TimeLimit<ScriptEnv>;
+    using MO = gym::Monitor<TL, true>;
+    {
+        auto env = std::make_unique<MO>(std::make_unique<TL>(std::make_unique<ScriptEnv>(rew, dn), std::optional<size_t>((size_t)max_steps)),
+                                        std::numeric_limits<double>::max(), std::string("env7"), std::filesystem::path(out));
+        env->reset();
+        for (int64_t s = 0; s < steps; s++) { auto r = env->step(0); if (r.done) env->reset(); }
+    }   // the writer's ofstream closes here
+    return 0;
+}
+
 // in: int64 F (0 = scalar shape {}, as the return statistics, vec_normalize.h:57), int64 n, float x[n][max(F,1)].
 // out.pt: torch::save of the reference module after one update(x); <out.pt>.bin: mean[F'], var[F'], count as floats.
 int run_ckpt_save(const char* in, const char* out) {
@@ -116,9 +136,10 @@ int run_ckpt_load(const char* in, const char* out) {
 }  // namespace
 
 int main(int argc, char** argv) {
-    if (argc != 4) { fprintf(stderr, "usage: %s wrappers|rms|ckpt_save|ckpt_load <in> <out>\n", argv[0]); return 1; }
+    if (argc != 4) { fprintf(stderr, "usage: %s wrappers|rms|csv|ckpt_save|ckpt_load <in> <out>\n", argv[0]); return 1; }
     if (!strcmp(argv[1], "wrappers")) return run_wrappers(argv[2], argv[3]);
     if (!strcmp(argv[1], "rms")) return run_rms(argv[2], argv[3]);
+    if (!strcmp(argv[1], "csv")) return run_csv(argv[2], argv[3]);
     if (!strcmp(argv[1], "ckpt_save")) return run_ckpt_save(argv[2], argv[3]);
     if (!strcmp(argv[1], "ckpt_load")) return run_ckpt_load(argv[2], argv[3]);
     return 1;

@@ -85,7 +85,18 @@ def run_ckpt_load(in_pt):
     return v[:n], v[n:2 * n], float(v[2 * n])
 
 
+def run_csv(rew, done, max_steps, steps, out_csv):
+    """The reference's Monitor<TimeLimit<scripted env>> constructed with id "env7" and a file name -> its CSV log."""
+    with tempfile.TemporaryDirectory() as d:
+        fin = os.path.join(d, "in")
+        with open(fin, "wb") as f:
+            f.write(np.array([rew.size, max_steps, steps, 5], np.int64).tobytes()); f.write(rew.tobytes()); f.write(done.tobytes())
+        subprocess.run([DRIVER, "csv", fin, out_csv], check=True, capture_output=True)
+
+
 def main():
+    rew, done = wrapper_script(11, 997)
+    run_csv(rew, done, 13, 1500, os.path.join(OUT, "ref_monitor.csv"))
     # checkpoints written by the reference's own save(): observation statistics (F = 4) and the scalar return statistics
     for name, F, seed in (("observation", 4, 21), ("returns", 0, 22)):
         pt = os.path.join(OUT, f"ref_rms_checkpoint_{name}.pt")

@@ -148,3 +148,32 @@ def test_cartpole_f32_mode_short_horizon_and_counter_rng(oracle):
         assert err[valid].max() <= 1e-4
         bad += int((err[valid] > 1e-5).sum())
     assert valid.mean() >= 0.9999 and bad <= 0.002 * n * T * 4
+
+
+def test_monitor_csv_logs_the_finished_episodes_of_chosen_envs(oracle, tmp_path):
+    """Monitor(env, ..., id, fileName) per env (monitor.h:41-50,93-94): one CSV per logged env, rows (t, r, l) of its episodes."""
+    from gym_amd.monitor_csv import MonitorCsv
+    from gym_amd.vec_env import HipVecEnv
+    n, T, seed = 256, 150, 2
+    logged = [0, 5, 255]
+    env = MonitorCsv(HipVecEnv.make("CartPole-v1", n, max_episode_steps=500, monitor=True, tape_episodes=T // 8 + 4), str(tmp_path), logged)
+    env.seed(seed)
+    ov = oracle.vec(CARTPOLE, n, F_TIME_LIMIT | F_MONITOR, 500)
+    ov.seed(seed)
+    env.reset(); ov.reset()
+    acts = splitmix_actions(31, T, n, 2)
+    want = {i: [] for i in logged}
+    for t in range(T):
+        env.step(torch.from_numpy(acts[t]).cuda())
+        r = ov.step(acts[t])
+        for i in logged:
+            if r["done"][i]:
+                want[i].append((float(r["ep_r"][i]), float(r["ep_l"][i])))
+    env.close()
+    for i in logged:
+        text = open(tmp_path / f"env{i}.csv").read()
+        head, body = text.split("t,r,l", 1)
+        assert head.splitlines()[1] == f"id: env{i}"
+        rows = [tuple(float(x) for x in line.split(",")) for line in body.strip().split("\n")] if body.strip() else []
+        assert [(r_, l_) for _, r_, l_ in rows] == want[i] and len(rows) >= 3
+        assert all(b[0] >= a[0] for a, b in zip(rows, rows[1:]))                   # t is monotone

@@ -99,3 +99,32 @@ def test_checkpoint_round_trip_with_live_reference_code(tmp_path):
         save_running_mean_std(ours, got[0], got[1], got[2])
         back = R.run_ckpt_load(ours)
         assert np.array_equal(back[0], ref[0]) and np.array_equal(back[1], ref[1]) and np.float32(back[2]) == np.float32(ref[2])
+
+
+def test_monitor_csv_bytes_match_the_reference_writer(oracle, tmp_path):
+    """(f3) Monitor's CSV log: tests/golden/ref_monitor.csv was written by the reference's ResultWriter (monitor.h:20-35).
+    Re-writing its rows through gym_amd.monitor_csv.ResultWriter reproduces the file byte for byte (header without a
+    trailing newline, %g floats), and the (r, l) columns equal the oracle's Monitor over the same script."""
+    from gym_amd.monitor_csv import ResultWriter
+    raw = open(os.path.join(G, "ref_monitor.csv"), "rb").read().decode()
+    head, body = raw.split("t,r,l", 1)
+    t_start = int(head.splitlines()[0].split(": ")[1]); env_id = head.splitlines()[1].split(": ")[1]
+    rows = [tuple(float(x) for x in line.split(",")) for line in body.strip().split("\n")]
+    w = ResultWriter(str(tmp_path / "again.whatever"), t_start, env_id)
+    for t, r, l in rows:
+        w.write(r, l, t)
+    w.close()
+    assert w.path.endswith("again.csv")
+    assert open(w.path, "rb").read().decode() == raw
+    # the episodes themselves: TimeLimit(13) + Monitor over the scripted env, 1500 steps
+    rew, done = R.wrapper_script(11, 997)
+    v = oracle.vec(SCRIPTED, 1, F_TIME_LIMIT | F_MONITOR, 13, script=(rew, done))
+    v.reset()
+    eps = []
+    for _ in range(1500):
+        o = v.step(np.zeros(1, np.int32))
+        if o["done"][0]:
+            eps.append((o["ep_r"][0], o["ep_l"][0]))
+    assert len(eps) == len(rows)
+    for (t, r, l), (er, el) in zip(rows, eps):
+        assert float("%g" % er) == r and float(el) == l
