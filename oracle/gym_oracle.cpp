@@ -565,3 +565,186 @@ int oracle_num_threads() {
 }
 
 }  // extern "C"
+
+// =============================================================================================
+// f4  The Atari wrapper chain around a host emulator, restated class by class the way the reference composes it
+//     (AtariWrapper::make, wrappers/atari_wrappers.cpp:68-121):
+//       AtariEnv -> NOOPResetEnv -> MaxAndSkipEnv -> Monitor -> EpisodicLifeEnv -> [FireResetEnv] -> WarpFrameEnv -> ClipRewardEnv
+//     under SyncVecEnv's auto-reset (sync_env.h:92-100).  The emulator is tests/cpp/fake_emulator.h (a scripted stand-in
+//     with ALE's call surface: no ROMs or ALE in this image).  Used to check the product's host Atari front-end.
+//     PARITY UNPINNED: the reference's chain needs ALE + OpenCV to build; restated from source, with the INTENDED
+//     MaxAndSkip semantics (two distinct frames).  Buffers that the reference leaves as empty cv::Mat
+//     before the first full frame-skip group start as an all-index-0 screen here (the reference would fail in cv::max).
+// =============================================================================================
+#include "../tests/cpp/fake_emulator.h"
+
+namespace oracle_atari {
+using oracle::area_resize_gray;
+using oracle::gray_u8;
+
+using Frame = std::vector<uint8_t>;   // RGB bytes [H][W][3] below WarpFrame, gray [84][84] above
+struct Resp { Frame obs; float reward = 0.f; bool done = false; int lives = 0; bool has_ep = false; float ep_r = 0.f, ep_l = 0.f; };
+struct Env {
+    virtual ~Env() = default;
+    virtual Frame reset() = 0;
+    virtual Resp step(int action) = 0;
+};
+
+// AtariEnv<true> (atari/atari_env.cpp:11-23,101-113) with getScreenRGB2 colouring (atari/ale_c_wrapper.cpp:28-41), frameSkip 1
+struct BaseEnv : Env {
+    FakeEmulator emu; const uint32_t* pal;
+    BaseEnv(uint64_t game, const uint32_t* palette) : emu(game), pal(palette) {}
+    Frame colour() const {
+        Frame f((size_t)FakeEmulator::H * FakeEmulator::W * 3);
+        const uint8_t* s = emu.screen();
+        for (size_t p = 0; p < (size_t)FakeEmulator::H * FakeEmulator::W; p++) {
+            const uint32_t z = pal[s[p]];
+            f[3 * p] = (z >> 16) & 0xff; f[3 * p + 1] = (z >> 8) & 0xff; f[3 * p + 2] = z & 0xff;
+        }
+        return f;
+    }
+    Frame reset() override { emu.reset_game(); return colour(); }
+    Resp step(int a) override { Resp r; r.reward = (float)emu.act(a); r.obs = colour(); r.done = emu.game_over(); r.lives = emu.lives(); return r; }
+};
+struct NoopResetEnv : Env {   // noop_reset.h:43-58
+    Env* in; std::mt19937 dev; int noop_max;
+    NoopResetEnv(Env* e, uint64_t seed, int nm) : in(e), dev((std::mt19937::result_type)seed), noop_max(nm) {}
+    Frame reset() override {
+        Resp resp; resp.obs = in->reset();
+        int noops = std::uniform_int_distribution<int>(1, noop_max + 1)(dev);
+        while (noops-- > 0) { resp = in->step(0); if (resp.done) resp.obs = in->reset(); }
+        return resp.obs;
+    }
+    Resp step(int a) override { return in->step(a); }
+};
+struct MaxAndSkipEnv : Env {   // atari_wrappers.cpp:10-33
+    Env* in; int skip; Frame buf[2];
+    MaxAndSkipEnv(Env* e, int s, const Frame& blank) : in(e), skip(s) { buf[0] = blank; buf[1] = blank; }
+    Frame reset() override { return in->reset(); }
+    Resp step(int a) override {
+        float total = 0.f; Resp resp; int t = 0;
+        while (t < skip) {
+            resp = in->step(a);
+            if (t == skip - 2) buf[0] = std::move(resp.obs); else if (t == skip - 1) buf[1] = std::move(resp.obs);
+            total += resp.reward;
+            if (resp.done) break;
+            t++;
+        }
+        resp.obs.resize(buf[0].size());
+        for (size_t k = 0; k < buf[0].size(); k++) resp.obs[k] = std::max(buf[0][k], buf[1][k]);   // cv::max
+        resp.reward = total;
+        return resp;
+    }
+};
+struct MonitorEnv : Env {   // monitor.h:57-102
+    Env* in; std::vector<float> rewards; int steps = 0;
+    explicit MonitorEnv(Env* e) : in(e) {}
+    Frame reset() override { Frame f = in->reset(); rewards.clear(); steps = 0; return f; }
+    Resp step(int a) override {
+        Resp r = in->step(a);
+        rewards.push_back(r.reward); steps++;
+        if (r.done) { r.has_ep = true; r.ep_r = std::accumulate(rewards.begin(), rewards.end(), 0.f); r.ep_l = (float)steps; }
+        return r;
+    }
+};
+struct EpisodicLifeEnv : Env {   // atari_wrappers.cpp:35-53, episodic_life.h:16-17
+    Env* in; BaseEnv* parent; int lives = 0; bool was_real_done = true;
+    EpisodicLifeEnv(Env* e, BaseEnv* p) : in(e), parent(p) {}
+    Resp step(int a) override {
+        Resp r = in->step(a);
+        was_real_done = r.done;
+        if (0 < r.lives && r.lives < lives) r.done = true;
+        lives = r.lives;
+        return r;
+    }
+    Frame reset() override {
+        Frame out = was_real_done ? in->reset() : in->step(0).obs;
+        lives = parent->emu.lives();
+        return out;
+    }
+};
+struct FireResetEnv : Env {   // atari_wrappers.cpp:55-67
+    Env* in;
+    explicit FireResetEnv(Env* e) : in(e) {}
+    Frame reset() override {
+        in->reset();
+        Resp r = in->step(1);
+        if (r.done) in->reset();
+        r = in->step(2);
+        if (r.done) in->reset();
+        return r.obs;
+    }
+    Resp step(int a) override { return in->step(a); }
+};
+struct WarpFrameEnv : Env {   // warp_frame.h:41-47
+    Env* in;
+    explicit WarpFrameEnv(Env* e) : in(e) {}
+    static Frame warp(const Frame& rgb) {
+        const int H = FakeEmulator::H, W = FakeEmulator::W;
+        std::vector<uint8_t> g((size_t)H * W);
+        for (size_t p = 0; p < g.size(); p++) g[p] = gray_u8(rgb[3 * p], rgb[3 * p + 1], rgb[3 * p + 2], 1);
+        Frame out(84 * 84);
+        area_resize_gray(g.data(), H, W, out.data(), 84, 84);
+        return out;
+    }
+    Frame reset() override { return warp(in->reset()); }
+    Resp step(int a) override { Resp r = in->step(a); r.obs = warp(r.obs); return r; }
+};
+struct ClipRewardEnv : Env {   // clip_reward.h:22-24
+    Env* in;
+    explicit ClipRewardEnv(Env* e) : in(e) {}
+    Frame reset() override { return in->reset(); }
+    Resp step(int a) override { Resp r = in->step(a); r.reward = r.reward == 0.f ? r.reward : (r.reward > 0.f ? 1.f : -1.f); return r; }
+};
+
+struct Chain {
+    std::vector<std::unique_ptr<Env>> owned;
+    Env* top = nullptr;
+    template <class T, class... A> T* add(A&&... a) { auto p = std::make_unique<T>(std::forward<A>(a)...); T* raw = p.get(); owned.push_back(std::move(p)); return raw; }
+};
+struct VecChain { std::vector<Chain> envs; std::vector<uint32_t> palette; };
+}  // namespace oracle_atari
+
+extern "C" {
+
+void* oracle_atari_chain_create(int64_t n, uint64_t seed, uint64_t game_base, int frame_skip, int noop_max, int life_loss, int fire, int clip,
+                                const uint32_t* zrgb256) {
+    using oracle_atari::BaseEnv; using oracle_atari::Chain; using oracle_atari::Frame; using oracle_atari::VecChain;
+    auto* v = new VecChain();
+    v->palette.assign(zrgb256, zrgb256 + 256);
+    v->envs.resize(n);
+    for (int64_t i = 0; i < n; i++) {
+        Chain& c = v->envs[i];
+        BaseEnv* base = c.add<BaseEnv>(game_base + (uint64_t)i, v->palette.data());
+        Frame blank((size_t)FakeEmulator::H * FakeEmulator::W * 3);
+        for (size_t p = 0; p < blank.size() / 3; p++) { const uint32_t z = v->palette[0]; blank[3 * p] = (z >> 16) & 0xff; blank[3 * p + 1] = (z >> 8) & 0xff; blank[3 * p + 2] = z & 0xff; }
+        oracle_atari::Env* e = c.add<oracle_atari::NoopResetEnv>(base, seed + (uint64_t)i, noop_max);
+        e = c.add<oracle_atari::MaxAndSkipEnv>(e, frame_skip, blank);
+        e = c.add<oracle_atari::MonitorEnv>(e);
+        if (life_loss) e = c.add<oracle_atari::EpisodicLifeEnv>(e, base);
+        if (fire) e = c.add<oracle_atari::FireResetEnv>(e);
+        e = c.add<oracle_atari::WarpFrameEnv>(e);
+        if (clip) e = c.add<oracle_atari::ClipRewardEnv>(e);
+        c.top = e;
+    }
+    return v;
+}
+void oracle_atari_chain_destroy(void* h) { delete (oracle_atari::VecChain*)h; }
+// SyncVecEnv::reset (sync_env.h:66-72): frames84 u8 [n][84*84]
+void oracle_atari_chain_reset(void* h, uint8_t* frames84) {
+    auto* v = (oracle_atari::VecChain*)h;
+    for (size_t i = 0; i < v->envs.size(); i++) { auto f = v->envs[i].top->reset(); std::memcpy(frames84 + i * 7056, f.data(), 7056); }
+}
+// SyncVecEnv::stepWait with auto-reset (sync_env.h:89-105)
+void oracle_atari_chain_step(void* h, const int32_t* actions, uint8_t* frames84, float* reward, uint8_t* done, uint8_t* has_ep, float* ep_r, float* ep_l,
+                             int32_t* lives) {
+    auto* v = (oracle_atari::VecChain*)h;
+    for (size_t i = 0; i < v->envs.size(); i++) {
+        auto r = v->envs[i].top->step(actions[i]);
+        if (r.done) r.obs = v->envs[i].top->reset();
+        std::memcpy(frames84 + i * 7056, r.obs.data(), 7056);
+        reward[i] = r.reward; done[i] = r.done; has_ep[i] = r.has_ep; ep_r[i] = r.ep_r; ep_l[i] = r.ep_l; lives[i] = r.lives;
+    }
+}
+
+}  // extern "C"

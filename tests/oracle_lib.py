@@ -41,6 +41,11 @@ class Oracle:
         l.oracle_vec_create.restype = _vp
         l.oracle_vec_create.argtypes = [C.c_int, _i64, C.c_int, _i64, C.c_int, _vp, _vp, _i64]
         l.oracle_vec_destroy.argtypes = [_vp]
+        l.oracle_atari_chain_create.restype = _vp
+        l.oracle_atari_chain_create.argtypes = [_i64, _u64, _u64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
+        l.oracle_atari_chain_destroy.argtypes = [_vp]
+        l.oracle_atari_chain_reset.argtypes = [_vp, _vp]
+        l.oracle_atari_chain_step.argtypes = [_vp] * 9
         l.oracle_vec_obs_dim.argtypes = [_vp]
         l.oracle_vec_seed.argtypes = [_vp, _u64]
         l.oracle_vec_set_reset_tape.argtypes = [_vp, _vp, _i64]
@@ -132,6 +137,10 @@ class Oracle:
     def framestack_update(self, stack, frame):
         n, hw, k = stack.shape[0], frame[0].size, stack.shape[-1]
         self.lib.oracle_framestack_update(_p(stack), _p(np.ascontiguousarray(frame)), n, hw, k)
+
+    def atari_chain(self, n, seed, game_base, palette, frame_skip=4, noop_max=30, life_loss=True, fire=False, clip=True):
+        """The reference's Atari wrapper chain (AtariWrapper::make) over the scripted emulator, n envs, SyncVecEnv auto-reset."""
+        return AtariChain(self.lib, n, seed, game_base, np.ascontiguousarray(palette, np.uint32), frame_skip, noop_max, life_loss, fire, clip)
 
     def norm_permute(self, nhwc):
         n, h, w, k = nhwc.shape
@@ -241,3 +250,28 @@ def splitmix_actions(seed, T, n, n_actions):
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
     return (z % np.uint64(n_actions)).astype(np.uint8).reshape(T, n)
+
+
+class AtariChain:
+    def __init__(self, lib, n, seed, game_base, palette, frame_skip, noop_max, life_loss, fire, clip):
+        self.lib, self.n = lib, n
+        self.h = lib.oracle_atari_chain_create(n, seed, game_base, frame_skip, noop_max, int(life_loss), int(fire), int(clip), _p(palette))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.oracle_atari_chain_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        fr = np.empty((self.n, 84, 84), np.uint8)
+        self.lib.oracle_atari_chain_reset(self.h, _p(fr))
+        return fr
+
+    def step(self, actions):
+        n = self.n
+        out = dict(frame=np.empty((n, 84, 84), np.uint8), reward=np.empty(n, np.float32), done=np.empty(n, np.uint8), has_ep=np.empty(n, np.uint8),
+                   ep_r=np.empty(n, np.float32), ep_l=np.empty(n, np.float32), lives=np.empty(n, np.int32))
+        a = np.ascontiguousarray(actions, np.int32)
+        self.lib.oracle_atari_chain_step(self.h, _p(a), _p(out["frame"]), _p(out["reward"]), _p(out["done"]), _p(out["has_ep"]), _p(out["ep_r"]),
+                                         _p(out["ep_l"]), _p(out["lives"]))
+        return out

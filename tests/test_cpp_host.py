@@ -10,12 +10,13 @@ from tests.oracle_lib import CARTPOLE, MOUNTAINCAR, F_CLIP_REWARD, F_MONITOR, F_
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "cpp", "bin", "hip_vec_env_demo")
+FE_BIN = os.path.join(ROOT, "tests", "cpp", "bin", "atari_frontend_demo")
 
 
 def test_cpp_mirror_compiles_and_links():
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert os.path.exists(BIN)
+    assert os.path.exists(BIN) and os.path.exists(FE_BIN)
 
 
 def _run(env, n, steps, norm, ckpt_dir=None):
@@ -62,3 +63,56 @@ def test_cpp_training_loop_matches_oracle(oracle, env, norm, tmp_path):
         assert om.shape == (F,) and rm.shape == ()
         assert np.allclose(om, st[:F], rtol=1e-5, atol=1e-7) and np.allclose(ov_, st[F:2 * F], rtol=1e-5) and oc == st[2 * F]
         assert np.isclose(float(rm), st[2 * F + 1], rtol=1e-5) and np.isclose(float(rv), st[2 * F + 2], rtol=1e-5) and rc == st[2 * F + 3]
+
+
+def _fake_palette():
+    """The demo's colour table: FakeEmulator::mix(77 + k) & 0xFFFFFF on even entries, 0 on odd ones."""
+    def mix(z):
+        m = (1 << 64) - 1
+        z = (z + 0x9E3779B97F4A7C15) & m
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+        return z ^ (z >> 31)
+    return np.array([0 if k & 1 else mix(77 + k) & 0xFFFFFF for k in range(256)], np.uint32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("life_loss,fire", [(True, False), (True, True), (False, True)])
+def test_atari_front_end_matches_the_reference_chain(oracle, tmp_path, life_loss, fire):
+    """(f4) gym::AtariFrontEnd — NOOP / MaxAndSkip / Monitor / EpisodicLife / FireReset control flow on the host, pinned
+    double-buffered upload of palette-index screens, colour + max + warp + frame stack + permute on the GPU — against the
+    oracle's class-by-class restatement of AtariWrapper::make under SyncVecEnv auto-reset, over a scripted emulator."""
+    assert os.path.exists(FE_BIN), "build tests/cpp first"
+    n, T, seed = 6, 90, 4
+    out = tmp_path / "fe.bin"
+    r = subprocess.run([FE_BIN, str(n), str(T), str(seed), str(int(life_loss)), str(int(fire)), str(out)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stderr[-2000:])
+    raw = np.fromfile(out, np.uint8)
+    assert tuple(raw[:16].view(np.int64)) == (n, T)
+    pos = 16
+    def take(count, dt):
+        nonlocal pos
+        nbytes = count * np.dtype(dt).itemsize
+        v = raw[pos:pos + nbytes].view(dt); pos += nbytes
+        return v
+    chain = oracle.atari_chain(n, seed, 1000, _fake_palette(), life_loss=life_loss, fire=fire)
+    stack = np.zeros((n, 84, 84, 4), np.uint8)
+    f0 = chain.reset()
+    oracle.framestack_reset(stack, f0)
+    assert np.array_equal(take(n * 7056, np.uint8).reshape(n, 84, 84), f0)
+    dones = eps = life_dones = 0
+    for t in range(T):
+        a = (np.arange(n) * 7 + t * 3) % 6
+        o = chain.step(a)
+        oracle.framestack_update(stack, o["frame"])
+        assert np.array_equal(take(n * 7056, np.uint8).reshape(n, 84, 84), o["frame"]), t
+        assert np.array_equal(take(n, np.float32), o["reward"]), t
+        assert np.array_equal(take(n, np.uint8), o["done"]), t
+        assert np.array_equal(take(n, np.uint8), o["has_ep"]), t
+        assert np.array_equal(take(n, np.float32), o["ep_r"]) and np.array_equal(take(n, np.float32), o["ep_l"]), t
+        assert np.array_equal(take(n, np.int32), o["lives"]), t
+        dones += int(o["done"].sum()); eps += int(o["has_ep"].sum()); life_dones += int((o["done"] & ~o["has_ep"]).sum())
+    final = take(n * 4 * 7056, np.uint8).reshape(n, 4, 84, 84)
+    assert np.array_equal(final, stack.transpose(0, 3, 1, 2))                       # VecNormAndPermute view of the VecFrameStack
+    assert pos == raw.size
+    assert eps >= 2 and dones >= eps and (life_dones > 0) == life_loss              # the script exercised the branches
