@@ -207,6 +207,56 @@ def main():
                 "bytes_per_env_step": bps, "achieved_GBs": round(bps * n3 * steps / dt / 1e9, 1), "collective": "all_reduce(12 x f64)/step" if world > 1 else None,
                 "obs_count": float(stats[4])}
 
+    def measure_pcie_inclusive(steps):
+        """What the rates become if a caller keeps actions / results / frames on the HOST (never `value`):
+        (a) the headline CartPole step with int32 actions from pinned host memory and obs/reward/done copied back to it;
+        (b) the Atari step with palette-index screens uploaded from pinned host memory every step."""
+        out = {}
+        eng, acts = build("cartpole", "lockstep")
+        h_act = torch.empty(n, dtype=torch.int32).pin_memory()
+        h_act.copy_(acts[0].cpu())
+        d_act = torch.empty(n, dtype=torch.int32, device="cuda")
+        h_obs, h_rew, h_done = (torch.empty(sh, dtype=torch.float32).pin_memory() for sh in ((n, 4), (n,), (n,)))
+        def host_step():
+            d_act.copy_(h_act, non_blocking=True)
+            eng.step(d_act)
+            h_obs.copy_(eng.obs, non_blocking=True); h_rew.copy_(eng.reward, non_blocking=True); h_done.copy_(eng.done, non_blocking=True)
+        for _ in range(3):
+            host_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            host_step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out["cartpole_lockstep_host_actions_and_results"] = {"value": n / dt, "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 3),
+                                                             "pcie_bytes_per_env_step": 28, "pcie_GBs": round(28 * n / dt / 1e9, 1)}
+        eng.close()
+        del eng, acts, d_act
+        torch.cuda.empty_cache()
+        from gym_amd.atari import AtariPreprocessor
+        n4 = 4096
+        pp = AtariPreprocessor(n4, device=local_rank)
+        pp.set_palette(torch.randint(0, 1 << 24, (256,), dtype=torch.int64, generator=torch.Generator().manual_seed(3)).numpy().astype("uint32"))
+        h_scr = (torch.randint(0, 128, (n4, 2, 210, 160), dtype=torch.uint8) * 2).pin_memory()
+        d_scr = torch.empty_like(h_scr, device="cuda")
+        d_scr.copy_(h_scr); pp.reset(d_scr)
+        def host_frames_step():
+            d_scr.copy_(h_scr, non_blocking=True)
+            pp.step(d_scr)
+        for _ in range(3):
+            host_frames_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            host_frames_step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out["atari_index_screens_from_host"] = {"value": n4 / dt, "unit": "env-steps/s", "ms_per_step": round(dt * 1e3, 3),
+                                                "pcie_bytes_per_env_step": 67200, "pcie_GBs": round(67200 * n4 / dt / 1e9, 1)}
+        pp.close()
+        return out
+
     def measure_atari(n4, steps):
         """BASELINE configs[3]: 4096 envs, MaxAndSkip max + WarpFrame 84x84 gray + FrameStack(4) ring write, synthetic frames."""
         from gym_amd.atari import AtariPreprocessor
@@ -328,6 +378,8 @@ def main():
         guarded("config3_mountaincar_vecnormalize_16M_per_gpu", measure_config3, 1 << 24, max(20, args.steps // 4))
         if rank == 0:
             guarded("config4_atari_preprocess_4096", measure_atari, 4096, max(20, args.steps // 4))
+        if rank == 0 and world == 1:
+            guarded("pcie_inclusive_never_value", measure_pcie_inclusive, 10)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
