@@ -257,6 +257,10 @@ template <> struct EnvTraits<KIND_MOUNTAINCAR> { static constexpr int F = 2; sta
 #ifndef GYMHIP_PIPE
 #define GYMHIP_PIPE 1
 #endif
+//   GYMHIP_TAPE_NT 1 = non-temporal load for the reset-tape gather
+#ifndef GYMHIP_TAPE_NT
+#define GYMHIP_TAPE_NT 0
+#endif
 using f32x4 = float __attribute__((ext_vector_type(4)));
 using f32x2 = float __attribute__((ext_vector_type(2)));
 using i32x4 = int32_t __attribute__((ext_vector_type(4)));
@@ -333,7 +337,11 @@ __device__ inline void reset_state(const StepParams& p, int64_t i, int64_t ep, T
     if constexpr (KIND == KIND_CARTPOLE) {
         float r[4];
         if (p.reset_mode == GYMHIP_RESET_TAPE) {
-            float4 v = ((const float4*)p.tape)[ep * p.n + i];
+#if GYMHIP_TAPE_NT
+            f32x4 v = __builtin_nontemporal_load((const f32x4*)p.tape + (ep * p.n + i));   // each row is read once: do not keep its line
+#else
+            f32x4 v = ((const f32x4*)p.tape)[ep * p.n + i];
+#endif
             r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
         } else {
             counter_reset_draw(p.seed, p.env_offset + i, ep, r);
