@@ -53,6 +53,14 @@ int main(int argc, char** argv) {
         eval_env->load(argv[5]);
         auto a = trained->normStats().cpu(), b = eval_env->normStats().cpu();
         std::printf("ckpt %d\n", (int)torch::equal(a, b));
+        // Updateable::update (vec_normalize.h:191-206) and reset(int index) (vec_normalize.h:179-189) through the mirror
+        const int64_t F = cart ? 4 : 2;
+        auto rows = torch::full({3, n, F}, 0.25f), rew = torch::full({3, n}, -1.0f);
+        const float count_before = trained->normStats().cpu()[2 * F].item<float>();
+        trained->update(rows, rew);
+        auto st = trained->normStats().cpu();
+        auto row = env->reset(5);
+        std::printf("update %d %d\n", (int)(st[2 * F].item<float>() == count_before + 3.0f * n), (int)(row.dim() == 1 && row.size(0) == F));
     }
     return 0;
 }

@@ -40,8 +40,8 @@ def test_cpp_training_loop_matches_oracle(oracle, env, norm, tmp_path):
     if norm:
         # the C++ mirror's save(): files in the reference's archive format, reloaded by its own load() and readable here
         from gym_amd.checkpoint import load_running_mean_std
-        assert lines[-1] == ["ckpt", "1"]
-        lines = lines[:-1]
+        assert lines[-2] == ["ckpt", "1"] and lines[-1] == ["update", "1", "1"]
+        lines = lines[:-2]
     obs0 = v.norm_reset()[0] if norm else v.reset()
     assert lines[0][0] == "reset" and np.isclose(float(lines[0][1]), obs0.astype(np.float64).sum(), rtol=1e-6, atol=1e-3)
     idx = np.arange(n, dtype=np.int64)
