@@ -207,6 +207,39 @@ def main():
                 "bytes_per_env_step": bps, "achieved_GBs": round(bps * n3 * steps / dt / 1e9, 1), "collective": "all_reduce(12 x f64)/step" if world > 1 else None,
                 "obs_count": float(stats[4])}
 
+    def measure_config2():
+        """BASELINE configs[1]: CartPole N = 65,536, lockstep, tape resets.  (a) one launch per VecEnv::step — 5.5 MB per
+        launch, i.e. launch-latency-bound, no roofline fraction to show; (b) the rollout form, K = 500 steps per launch
+        from a u8 action tape with the state held in registers (what the parity test of this config uses)."""
+        n2, K = 65536, 500
+        eng = Engine(EngineConfig(env_kind=L.ENV_CARTPOLE, n_envs=n2, precision=L.PRECISION_LOCKSTEP_F64, reset_mode=L.RESET_TAPE,
+                                  wrappers=L.WRAP_TIME_LIMIT | L.WRAP_MONITOR, max_episode_steps=500, env_offset=rank * n2, seed=0), local_rank)
+        eng.generate_reset_tape((3 * K + 2000) // 8 + 2)
+        eng.reset()
+        g = torch.Generator(device="cuda").manual_seed(7 + rank)
+        a32 = torch.randint(0, 2, (n2,), dtype=torch.int32, device="cuda", generator=g)
+        tape = torch.randint(0, 2, (K, n2), dtype=torch.uint8, device="cuda", generator=g)
+        for _ in range(100):
+            eng.step(a32)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(1000):
+            eng.step(a32)
+        torch.cuda.synchronize()
+        per_step = (time.perf_counter() - t0) / 1000
+        eng.rollout(tape)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            eng.rollout(tape)
+        torch.cuda.synchronize()
+        roll = (time.perf_counter() - t0) / (2 * K)
+        err = eng.poll_error()
+        eng.close()
+        return {"envs": n2, "step_api": {"value": n2 / per_step, "unit": "env-steps/s (per GPU)", "us_per_step": round(per_step * 1e6, 2)},
+                "rollout_500_steps_per_launch": {"value": n2 / roll, "unit": "env-steps/s (per GPU)", "us_per_step": round(roll * 1e6, 3)},
+                "error_flag": err}
+
     def measure_pcie_inclusive(steps):
         """What the rates become if a caller keeps actions / results / frames on the HOST (never `value`):
         (a) the headline CartPole step with int32 actions from pinned host memory and obs/reward/done copied back to it;
@@ -374,6 +407,7 @@ def main():
     if not args.no_extra and args.env == "cartpole" and args.mode == "lockstep":
         for env, mode in (("cartpole", "f32"), ("mountaincar", "lockstep"), ("mountaincar", "f32")):
             guarded(f"{env}_{mode}", classic, env, mode)
+        guarded("config2_cartpole_lockstep_65536", measure_config2)
         guarded("config3_mountaincar_vecnormalize_1M_per_gpu", measure_config3, 1 << 20, args.steps)
         guarded("config3_mountaincar_vecnormalize_16M_per_gpu", measure_config3, 1 << 24, max(20, args.steps // 4))
         if rank == 0:
