@@ -735,8 +735,16 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepParams p, con
         int t = CounterWord<KIND>::steps_now(w);
         uint32_t cursor = CounterWord<KIND>::cursor(w);
         float reward = 0.f; bool done = false; uint32_t rec = w;
+        // the action tape is read four steps ahead: at one wave per SIMD (N = 65,536) nothing else hides the load latency
+        constexpr int AHEAD = 4;
+        int next_action[AHEAD];
+#pragma unroll
+        for (int d = 0; d < AHEAD; d++) next_action[d] = d < K ? (int)tape[(int64_t)d * p.n + i] : 0;
         for (int64_t k = 0; k < K; k++) {
-            const int action = (int)tape[k * p.n + i];
+            const int action = next_action[0];
+#pragma unroll
+            for (int d = 0; d + 1 < AHEAD; d++) next_action[d] = next_action[d + 1];
+            next_action[AHEAD - 1] = k + AHEAD < K ? (int)tape[(k + AHEAD) * p.n + i] : 0;
             bool env_done;
             if constexpr (KIND == KIND_CARTPOLE) env_done = cartpole_step(s, action, t); else env_done = mountaincar_step(s, action);
             t += 1;
