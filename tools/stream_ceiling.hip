@@ -50,6 +50,20 @@ __global__ __launch_bounds__(256) void pattern_kernel(const u32x4* __restrict__ 
             __builtin_nontemporal_store(b.y, small_out + n + i);
             __builtin_nontemporal_store(a.z ^ b.w, small_out + 2 * n + i);
         }
+    } else if (WIDE == 2) {
+        // block-contiguous: block b owns envs [b * chunk, (b + 1) * chunk) and walks them tile by tile
+        const int64_t chunk = (n + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+            u32x4 a = __builtin_nontemporal_load(big_in + i), b = __builtin_nontemporal_load(big_in + n + i);
+            uint32_t c = __builtin_nontemporal_load(small_in + i), d = __builtin_nontemporal_load(small_in + n + i);
+            a += c; b += d;
+            __builtin_nontemporal_store(a, big_out + i);
+            __builtin_nontemporal_store(b, big_out + n + i);
+            __builtin_nontemporal_store(a.x, small_out + i);
+            __builtin_nontemporal_store(b.y, small_out + n + i);
+            __builtin_nontemporal_store(a.z ^ b.w, small_out + 2 * n + i);
+        }
     } else {
         for (int64_t base = (int64_t)blockIdx.x * 1024; base < n; base += (int64_t)gridDim.x * 1024) {
             u32x4 a[4], b[4];
@@ -133,6 +147,7 @@ int main(int argc, char** argv) {
         run<2, 2, true>("2R:2W nt", in, out, sink, n, grid);
         run_pattern<0>("step pattern 84 B, 4-B lanes", in, out, n, grid);
         run_pattern<1>("step pattern 84 B, 16-B groups", in, out, n, grid);
+        run_pattern<2>("step pattern 84 B, block-contiguous", in, out, n, grid);
     }
     CK(hipFree(in)); CK(hipFree(out)); CK(hipFree(sink));
     return 0;
