@@ -12,7 +12,10 @@
 // (ii) libstdc++'s own std::mt19937 / uniform_real_distribution<float>, which this file calls directly
 // exactly as the reference does, and (iii) hand-derived known answers in tests/.  Rows A4, A5, A8, A9
 // (TimeLimit, ClipReward, Monitor, RunningMeanStd) ARE pinned against the reference's own headers
-// compiled in place by oracle/Makefile (target _ref) when /root/reference is present.
+// compiled in place by oracle/Makefile (target _ref) when /root/reference is present; the same build pins the
+// VecNormalize checkpoint format (torch::save/load of RunningMeanStd, both directions) and Monitor's CSV bytes
+// (ResultWriter).  The Atari wrapper chain at the end of this file (row f4) is parity unpinned as well: the
+// reference's chain needs ALE and OpenCV.
 //
 // Every function cites the reference file:line it restates.  Compile WITHOUT fast-math and WITHOUT FMA
 // contraction (-ffp-contract=off, no -march=native): the reference is built by g++ for baseline x86-64.
