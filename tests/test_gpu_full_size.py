@@ -89,3 +89,33 @@ def test_mountaincar_normalised_16m_envs_determinism_and_float32_count():
     assert st[4] == count                                                           # obs count: float32 accumulation, as in the reference
     assert -0.6 < st[0] < -0.4 and abs(st[1]) < 0.01 and (st[2:4] > 0).all()        # mean position near the start, tiny mean velocity
     assert torch.isfinite(a.obs_norm).all() and float(a.obs_norm.abs().max()) <= 10.0   # clip_obs
+
+
+def test_cartpole_lockstep_1m_envs_2000_steps_done_stream_exact(oracle):
+    """A longer soak than config 2: 1,048,576 envs x 2,000 steps = 2.1e9 env-steps through the rollout kernel, every
+    done / truncated flag compared with the oracle (bit-exact), observations at every chunk end (1e-5)."""
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+    n, T, chunk, seed = 1 << 20, 2000, 500, 3
+    gen = torch.Generator(device="cuda").manual_seed(99)
+    ov = oracle.vec(CARTPOLE, n, F_TIME_LIMIT | F_MONITOR, 500)
+    ov.seed(seed)
+    eng = Engine(EngineConfig(env_kind=L.ENV_CARTPOLE, n_envs=n, precision=L.PRECISION_LOCKSTEP_F64, reset_mode=L.RESET_TAPE,
+                              wrappers=L.WRAP_TIME_LIMIT | L.WRAP_MONITOR, max_episode_steps=500), 0)
+    eng.upload_reset_tape(oracle.cartpole_reset_tape(seed, n, T // 8 + 8))
+    eng.reset()
+    assert np.array_equal(eng.obs.cpu().numpy(), ov.reset())
+    rec_done = torch.empty((chunk, n), dtype=torch.uint8, device="cuda")
+    rec_trunc = torch.empty((chunk, n), dtype=torch.uint8, device="cuda")
+    episodes = 0
+    for c in range(T // chunk):
+        acts_dev = torch.randint(0, 2, (chunk, n), dtype=torch.uint8, device="cuda", generator=gen)
+        eng.rollout(acts_dev, rec_done, None, rec_trunc, None)
+        r = ov.rollout(acts_dev.cpu().numpy(), rec_reward=False)
+        assert np.array_equal(rec_done.cpu().numpy(), r["done"]), f"done stream diverged in chunk {c}"
+        assert np.array_equal(rec_trunc.cpu().numpy(), r["truncated"]), f"truncated stream diverged in chunk {c}"
+        assert np.allclose(eng.obs.cpu().numpy(), r["final_obs"], rtol=1e-5, atol=1e-7), c
+        episodes += int(r["done"].sum())
+    st = eng.state_f64().cpu().numpy()
+    assert np.abs(st - r["final_obs64"]).max() <= 1e-12 and (st == r["final_obs64"]).mean() >= 0.999
+    assert eng.poll_error() == 0 and eng.episode_stats()[0] == episodes
