@@ -184,9 +184,10 @@ private:
         c.precision = opt.lockstep ? GYMHIP_PRECISION_LOCKSTEP_F64 : GYMHIP_PRECISION_F32;
         const bool tape = opt.host_drawn_resets && opt.env_kind == GYMHIP_ENV_CARTPOLE;
         c.reset_mode = tape ? GYMHIP_RESET_TAPE : GYMHIP_RESET_COUNTER_RNG;
-        c.wrappers = (opt.max_episode_steps > 0 ? GYMHIP_WRAP_TIME_LIMIT : 0u) | (opt.clip_reward ? GYMHIP_WRAP_CLIP_REWARD : 0u) |
-                     (opt.monitor ? GYMHIP_WRAP_MONITOR : 0u) | (opt.norm_obs ? GYMHIP_WRAP_NORM_OBS : 0u) |
-                     (opt.norm_reward ? GYMHIP_WRAP_NORM_REWARD : 0u) | (opt.training ? GYMHIP_WRAP_NORM_TRAINING : 0u);
+        auto flag = [](bool on, uint32_t bit) { return on ? bit : 0u; };
+        c.wrappers = flag(opt.max_episode_steps > 0, GYMHIP_WRAP_TIME_LIMIT) | flag(opt.clip_reward, GYMHIP_WRAP_CLIP_REWARD) |
+                     flag(opt.monitor, GYMHIP_WRAP_MONITOR) | flag(opt.norm_obs, GYMHIP_WRAP_NORM_OBS) |
+                     flag(opt.norm_reward, GYMHIP_WRAP_NORM_REWARD) | flag(opt.training, GYMHIP_WRAP_NORM_TRAINING);
         c.max_episode_steps = opt.max_episode_steps;
         c.n_envs = opt.n_envs; c.env_offset = opt.env_offset; c.seed = seeded ? seed_value : 0;
         c.clip_obs = opt.clip_obs; c.clip_reward = opt.clip_rew; c.gamma = opt.gamma; c.epsilon = opt.epsilon;
