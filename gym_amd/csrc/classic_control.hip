@@ -46,7 +46,10 @@ using namespace gymhip;
 
 namespace {
 
-constexpr int kBlock = 256;
+#ifndef GYMHIP_BLOCK
+#define GYMHIP_BLOCK 256
+#endif
+constexpr int kBlock = GYMHIP_BLOCK;   // 512 and 1024 measured no better
 constexpr int kMaxGrid = 8192;  // upper bound of the grid-stride launch (sizes the per-block partial buffers)
 constexpr int kDefaultGrid = 1024;  // 256 CUs x 4 blocks: best of the 512..8192 sweep (profiles/r01_sweep.txt); GYMHIP_GRID overrides
 constexpr int kMaxCols = 16;    // >= 2F+6 for F=4
