@@ -542,7 +542,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
     block_reduce_store<3>(ep, p.ep_partials + (int64_t)blockIdx.x * 4, true);
 }
 
-// Initial reset (VecEnv::reset): episode 0 for every env.
+// VecEnv::reset(): every env starts a new episode.  In TAPE mode env i takes the tape row at its own cursor and advances it —
+// a CartPoleEnv's generator keeps running across resets (cartpole.cpp:21-26), so a second reset() draws the NEXT four
+// values, not the first four again.  A fresh workspace (or a freshly drawn tape) has every cursor at 0.
 template <int KIND, bool LOCKSTEP, bool NORM>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const StepParams p) {
     constexpr int F = EnvTraits<KIND>::F;
@@ -559,13 +561,21 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepParams p) {
     const StepBuffers& b = p.buf;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * kBlock) {
         T s[F];
-        reset_state<KIND, T>(p, i, p.reset_mode == GYMHIP_RESET_TAPE ? 0 : p.step_counter, s);
+        uint32_t cursor = 0;
+        int64_t e = p.step_counter;
+        if (KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE) {
+            cursor = CounterWord<KIND>::cursor(b.counter[i]);
+            e = cursor;
+            if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
+            cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
+        }
+        reset_state<KIND, T>(p, i, e, s);
         float o[F];
 #pragma unroll
         for (int f = 0; f < F; f++) o[f] = (float)s[f];
         if constexpr (LOCKSTEP) store_state<F>(b, i, s, o, p.error_flag);
         store_obs(b.obs, i, o);
-        b.counter[i] = CounterWord<KIND>::pack(0, (KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE) ? 1u : 0u, false, false);
+        b.counter[i] = CounterWord<KIND>::pack(0, cursor, false, false);
         b.reward[i] = 0.f;
         b.done[i] = 0.f;
         if (b.returns) b.returns[i] = 0.f;                        // vec_normalize.h:147
@@ -837,6 +847,14 @@ __global__ __launch_bounds__(kBlock) void read_state_kernel(const StepBuffers b,
 #pragma unroll
         for (int f = 0; f < F; f++) out[i * F + f] = s[f];
     }
+}
+
+// A (re)drawn tape restarts every env's stream (Env::seed re-seeds the generator, env.h:60-63): cursors back to 0, the
+// step counts and episode records of the counter words untouched.
+__global__ __launch_bounds__(kBlock) void rewind_tape_cursor_kernel(uint32_t* counter, int64_t n) {
+    using W = CounterWord<KIND_CARTPOLE>;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        counter[i] &= ~(W::kCursorMask << W::S);
 }
 
 __global__ __launch_bounds__(kBlock) void fill_tape_kernel(float4* tape, int64_t n, int64_t episodes, uint64_t seed, int64_t env_offset) {
@@ -1116,6 +1134,13 @@ int gymhip_seed(gymhip_engine* h, uint64_t seed) {
     return GYMHIP_OK;
 }
 
+// every freshly loaded tape is read from row 0 again (see rewind_tape_cursor_kernel)
+static int rewind_tape_cursors(gymhip_engine* h, hipStream_t s) {
+    hipLaunchKernelGGL(rewind_tape_cursor_kernel, dim3(h->grid), dim3(kBlock), 0, s, h->at<uint32_t>(h->L.counter), h->cfg.n_envs);
+    HIP_TRY(hipGetLastError());
+    return GYMHIP_OK;
+}
+
 static int ensure_tape(gymhip_engine* h, int64_t episodes) {
     if (h->cfg.env_kind != KIND_CARTPOLE) return fail(GYMHIP_EINVAL, "only CartPole draws its reset state (MountainCar resets are constant)");
     if (episodes <= 0) return fail(GYMHIP_EINVAL, "episodes must be positive");
@@ -1132,7 +1157,10 @@ int gymhip_upload_reset_tape(gymhip_engine* h, const float* host_tape, int64_t e
     if (int rc = check_handle(h)) return rc;
     if (!host_tape) return fail(GYMHIP_EINVAL, "host_tape is null");
     if (int rc = ensure_tape(h, episodes)) return rc;
+    HIP_TRY(hipDeviceSynchronize());   // no stream argument here: nothing of this engine may still be reading the old rows
     HIP_TRY(hipMemcpy(h->tape, host_tape, (size_t)episodes * h->cfg.n_envs * 16, hipMemcpyHostToDevice));
+    if (int rc = rewind_tape_cursors(h, nullptr)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
     return GYMHIP_OK;
 }
 
@@ -1168,7 +1196,10 @@ static int draw_reset_tape(gymhip_engine* h, bool seeded, uint64_t seed, int64_t
     }
     for (auto& th : pool) th.join();
     if (seeded) h->cfg.seed = seed;
+    HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h->tape, tape.data(), tape.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (int rc = rewind_tape_cursors(h, nullptr)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
     return GYMHIP_OK;
 }
 
@@ -1177,7 +1208,7 @@ int gymhip_generate_reset_tape(gymhip_engine* h, int64_t episodes, void* stream)
     if (int rc = ensure_tape(h, episodes)) return rc;
     hipLaunchKernelGGL(fill_tape_kernel, dim3(kMaxGrid), dim3(kBlock), 0, (hipStream_t)stream, (float4*)h->tape, h->cfg.n_envs, episodes, h->cfg.seed, h->cfg.env_offset);
     HIP_TRY(hipGetLastError());
-    return GYMHIP_OK;
+    return rewind_tape_cursors(h, (hipStream_t)stream);
 }
 
 int gymhip_download_reset_tape(gymhip_engine* h, float* host_tape, int64_t episodes) {

@@ -48,6 +48,10 @@ public:
 
     std::vector<size_t> seed(size_t _seed) noexcept override {   // sync_env.h:74-83
         seeded = true; seed_value = _seed;
+        if (h) {   // mid-run re-seed: every env's generator restarts, exactly as Env::seed does (env.h:60-63)
+            const bool tape = opt.host_drawn_resets && opt.env_kind == GYMHIP_ENV_CARTPOLE;
+            ok(tape ? gymhip_seed_reset_tape(h, _seed, opt.tape_episodes) : gymhip_seed(h, _seed), "seed");
+        }
         std::vector<size_t> s(numEnvs);
         for (int i = 0; i < numEnvs; i++) s[i] = _seed + (size_t)opt.env_offset + (size_t)i;
         return s;

@@ -205,9 +205,12 @@ class HipVecEnv(VecEnv):
     # -- VecEnv interface ------------------------------------------------------------------------------------------
     def seed(self, _seed: int):
         """sync_env.h:74-83: env i <- _seed + i; returns the per-env seeds of this shard."""
-        if self.engine is not None:
-            raise RuntimeError("seed() must precede the first reset(): the reset tape is drawn from it")
         self._seed = int(_seed)
+        if self.engine is not None:   # mid-run re-seed: every env's generator restarts (env.h:60-63); the tape is redrawn, cursors rewound
+            if self._reset_mode == L.RESET_TAPE:
+                self.engine.seed_reset_tape(self._seed, self._tape_episodes)
+            else:
+                self.engine.seed(self._seed)
         return [self._seed + self.env_offset + i for i in range(self.numEnvs)] if self.numEnvs <= 1 << 20 else range(
             self._seed + self.env_offset, self._seed + self.env_offset + self.numEnvs)
 

@@ -110,7 +110,10 @@ int gymhip_seed(gymhip_engine* h, uint64_t seed);
 int gymhip_upload_reset_tape(gymhip_engine* h, const float* host_tape, int64_t episodes);
 /* VecEnv::seed(seed) for TAPE mode (sync_env.h:74-83): draws the tape ON THE HOST with std::mt19937(seed + env_offset + i)
  * and std::uniform_real_distribution<float>(-0.05f, 0.05f) — the reference's own generator, 4 draws per reset in order
- * (cartpole.cpp:21-26) — for `episodes` resets per env, and uploads it.  Call before gymhip_reset(). */
+ * (cartpole.cpp:21-26) — for `episodes` resets per env, and uploads it.  Every call that loads a tape (this one,
+ * _upload_, _unseeded_, _generate_) rewinds every env's tape cursor to row 0, as re-seeding restarts an env's generator
+ * (env.h:60-63); between loads the cursor runs on across auto-resets, gymhip_reset() and gymhip_reset_index(), as the
+ * generator does.  May be called again at any time (VecEnv::seed mid-run); synchronises the device. */
 int gymhip_seed_reset_tape(gymhip_engine* h, uint64_t seed, int64_t episodes);
 /* The same for envs that were never seeded: each keeps a default-constructed std::mt19937 (env.h:83), so — exactly as
  * in the reference — every env replays the same stream. */

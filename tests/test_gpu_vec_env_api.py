@@ -177,3 +177,35 @@ def test_monitor_csv_logs_the_finished_episodes_of_chosen_envs(oracle, tmp_path)
         rows = [tuple(float(x) for x in line.split(",")) for line in body.strip().split("\n")] if body.strip() else []
         assert [(r_, l_) for _, r_, l_ in rows] == want[i] and len(rows) >= 3
         assert all(b[0] >= a[0] for a, b in zip(rows, rows[1:]))                   # t is monotone
+
+
+def test_second_reset_and_midrun_reseed_follow_the_envs_generators(oracle):
+    """A CartPoleEnv's mt19937 keeps running across reset() calls (cartpole.cpp:21-26) and restarts on seed()
+    (env.h:60-63): a second VecEnv::reset() draws each env's NEXT four values, a mid-run seed() starts new streams."""
+    from gym_amd.vec_env import HipVecEnv
+    n, seed = 777, 9
+    env = HipVecEnv.make("CartPole-v1", n, max_episode_steps=500, monitor=True, tape_episodes=64)
+    env.seed(seed)
+    ov = oracle.vec(CARTPOLE, n, F_TIME_LIMIT | F_MONITOR, 500)
+    ov.seed(seed)
+    acts = splitmix_actions(5, 120, n, 2)
+
+    def run(t0, t1):
+        for t in range(t0, t1):
+            s = env.step(torch.from_numpy(acts[t].astype(np.int32)).cuda())
+            r = ov.step(acts[t])
+            assert np.array_equal(s.done.cpu().numpy()[:, 0], r["done"]), t
+            assert np.allclose(s.observation.cpu().numpy(), r["obs"], rtol=1e-5, atol=1e-7), t
+
+    first = env.reset().clone()
+    assert np.array_equal(first.cpu().numpy(), ov.reset())
+    run(0, 40)                                      # episodes end and auto-reset along the way: cursors differ per env
+    second = env.reset()
+    assert np.array_equal(second.cpu().numpy(), ov.reset()) and not torch.equal(first, second)
+    run(40, 80)
+    env.seed(seed + 1000)                           # mid-run: the NEXT reset of every env (auto or explicit) uses the new stream
+    ov.seed(seed + 1000)
+    run(80, 100)
+    assert np.array_equal(env.reset().cpu().numpy(), ov.reset())
+    run(100, 120)
+    assert env.engine.poll_error() == 0
