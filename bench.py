@@ -2,8 +2,10 @@
 """bench.py — env-steps/sec of the batched CartPole VecEnv step on MI355X (BASELINE.json metric).
 
 Workload (config.workload): BASELINE.json configs[4] CartPole leg — 16,777,216 envs per GPU, TimeLimit(500)+Monitor,
-fused step + in-kernel auto-reset, one `VecEnv::step` == one kernel launch, LOCKSTEP (fp64-state) arithmetic, i.e. the
-kernel whose streams are bit-exact against the CPU oracle (tests/test_gpu_classic_lockstep.py).  configs[1] (N=65,536)
+fused step + in-kernel auto-reset (reset states from the in-kernel counter RNG, as SURVEY.md §8d prescribes for this
+config; the host-drawn reset-tape variant is reported in `extra`), one `VecEnv::step` == one kernel launch, LOCKSTEP
+(fp64-state) arithmetic, i.e. the kernel whose streams are bit-exact against the CPU oracle for both reset sources
+(tests/test_gpu_classic_lockstep.py).  configs[1] (N=65,536)
 is the parity-test case: at 6.5 MB per step it is launch-latency-bound and cannot show a roofline fraction.
 Envs shard across GPUs with no data-path collective (weak scaling: per-GPU work fixed).
 
@@ -95,7 +97,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=16 * 1024 * 1024)
     ap.add_argument("--env", default="cartpole", choices=["cartpole", "mountaincar"])
     ap.add_argument("--mode", default="lockstep", choices=["lockstep", "f32"])
-    ap.add_argument("--reset-mode", default="tape", choices=["tape", "rng"], help="CartPole reset source (tape = lockstep-faithful)")
+    ap.add_argument("--reset-mode", default="rng", choices=["tape", "rng"],
+                    help="CartPole reset source: in-kernel counter RNG (SURVEY.md §8d config 5) or a device-resident reset tape (the form host-drawn mt19937 resets take)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (f32 / MountainCar) measurements")
@@ -131,14 +134,15 @@ def main():
         local_rank = 0
     n = args.envs_per_gpu
 
-    def build(env, mode):
+    def build(env, mode, reset_mode=None):
+        reset_mode = reset_mode or args.reset_mode
         kind = L.ENV_CARTPOLE if env == "cartpole" else L.ENV_MOUNTAINCAR
         wrappers = L.WRAP_TIME_LIMIT | L.WRAP_MONITOR | (L.WRAP_CLIP_REWARD if env == "mountaincar" else 0)
         cfg = EngineConfig(env_kind=kind, n_envs=n, precision=L.PRECISION_LOCKSTEP_F64 if mode == "lockstep" else L.PRECISION_F32,
-                           reset_mode=L.RESET_TAPE if (env == "cartpole" and args.reset_mode == "tape") else L.RESET_COUNTER_RNG, wrappers=wrappers,
+                           reset_mode=L.RESET_TAPE if (env == "cartpole" and reset_mode == "tape") else L.RESET_COUNTER_RNG, wrappers=wrappers,
                            max_episode_steps=500 if env == "cartpole" else 200, env_offset=rank * n, seed=0)
         eng = Engine(cfg, local_rank)
-        if env == "cartpole" and args.reset_mode == "tape":
+        if env == "cartpole" and reset_mode == "tape":
             # reset tape rows: every episode lasts >= 8 steps, so (W+K)/8 + 2 rows can never run out
             eng.generate_reset_tape((args.steps + args.warmup) // 8 + 2)
         eng.reset()
@@ -147,8 +151,8 @@ def main():
         acts = [torch.randint(0, n_act, (n,), dtype=torch.int32, device="cuda", generator=g) for _ in range(4)]
         return eng, acts
 
-    def measure(env, mode):
-        eng, acts = build(env, mode)
+    def measure(env, mode, reset_mode=None):
+        eng, acts = build(env, mode, reset_mode)
         dt, kern_ms = time_engine(torch, dist, eng, acts, args.steps, args.warmup, world)
         err = eng.poll_error()
         eps = eng.episode_stats()
@@ -345,8 +349,8 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            rec = json.load(open(tpath)).get(f"{args.env}_{args.mode}", {})
-            if rec.get("envs_per_launch") == n and args.reset_mode == "tape":
+            rec = json.load(open(tpath)).get(f"{args.env}_{args.mode}" + ("_tape" if args.reset_mode == "tape" and args.env == "cartpole" else ""), {})
+            if rec.get("envs_per_launch") == n:
                 traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -367,7 +371,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_m["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.mode == "lockstep" else "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.env} vec_env, {n} envs/GPU, TimeLimit+Monitor, fused step+auto-reset, {args.mode} arithmetic, "
+            "config": {"workload": f"{args.env} vec_env, {n} envs/GPU, TimeLimit+Monitor, fused step+auto-reset ({'in-kernel counter-RNG' if args.reset_mode == 'rng' else 'reset-tape'} resets), {args.mode} arithmetic, "
                                    f"one kernel launch per VecEnv::step (BASELINE configs[4])",
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": f"env-shard x{world}, no data-path collective",
                        "error_flag": main_m["error_flag"], "episodes_finished_rank0": main_m["episodes"]},
@@ -398,15 +402,18 @@ def main():
         except Exception as e:  # noqa: BLE001 — report, never lose the headline line
             extra[key] = {"error": f"{type(e).__name__}: {e}"}
 
-    def classic(env, mode):
-        m = measure(env, mode)
+    def classic(env, mode, reset_mode=None):
+        m = measure(env, mode, reset_mode)
         return {"value": m["value"], "unit": "env-steps/s", "kernel_ms": round(m["kernel_ms"], 4),
                 "bytes_per_env_step": m["bytes_per_env_step"], "achieved_GBs": round(m["achieved_gbs"], 1),
                 "frac": round(m["achieved_gbs"] / HBM_PEAK_GBS, 4)}
 
     if not args.no_extra and args.env == "cartpole" and args.mode == "lockstep":
+        other = "tape" if args.reset_mode == "rng" else "rng"
+        guarded(f"cartpole_lockstep_{other}_resets", classic, "cartpole", "lockstep", other)
         for env, mode in (("cartpole", "f32"), ("mountaincar", "lockstep"), ("mountaincar", "f32")):
             guarded(f"{env}_{mode}", classic, env, mode)
+        guarded(f"cartpole_f32_{other}_resets", classic, "cartpole", "f32", other)
         guarded("config2_cartpole_lockstep_65536", measure_config2)
         guarded("config3_mountaincar_vecnormalize_1M_per_gpu", measure_config3, 1 << 20, args.steps)
         guarded("config3_mountaincar_vecnormalize_16M_per_gpu", measure_config3, 1 << 24, max(20, args.steps // 4))

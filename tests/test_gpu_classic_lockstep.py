@@ -212,3 +212,50 @@ def test_reset_tape_exhaustion_sets_error_flag(oracle):
     for _ in range(60):
         eng.step(a)
     assert eng.poll_error() & 1
+
+
+def test_cartpole_lockstep_counter_rng_resets_replayed_by_oracle(oracle):
+    """COUNTER_RNG resets (bench.py's headline reset source): the reset states come from an
+    in-kernel counter hash, so the oracle cannot draw them — it REPLAYS them.  Every reset observation the engine
+    produced (exact: a reset state is four floats widened to double) is collected, per env and in order of use, into
+    a reset tape, and the oracle re-runs the whole trajectory from it.  done / truncated / episode records bit-exact,
+    obs within 1e-5, the fp64 state at the end within 1e-12."""
+    from gym_amd import _lib as L
+    n, T = 4096, 700
+    eng = make_engine(L.ENV_CARTPOLE, n, L.PRECISION_LOCKSTEP_F64, L.WRAP_TIME_LIMIT | L.WRAP_MONITOR, 500, reset_mode=L.RESET_COUNTER_RNG, seed=5)
+    eng.reset()
+    obs0 = eng.obs.cpu().numpy().copy()
+    assert (obs0 >= -0.05).all() and (obs0 < 0.05).all() and len(np.unique(obs0)) > 0.99 * obs0.size
+    tape = np.zeros((T // 8 + 3, n, 4), np.float32)
+    used = np.ones(n, np.int64)
+    tape[0] = obs0
+    acts = splitmix_actions(77, T, n, 2)
+    acts_dev = torch.from_numpy(acts.astype(np.int32)).cuda()
+    g_obs, g_done, g_info = [], [], []
+    for t in range(T):
+        eng.step(acts_dev[t])
+        o = eng.obs.cpu().numpy().copy()
+        d = eng.done.cpu().numpy() != 0
+        idx = np.nonzero(d)[0]
+        assert (o[idx] >= -0.05).all() and (o[idx] < 0.05).all()         # the rows of done envs ARE their reset states
+        tape[used[idx], idx] = o[idx]
+        used[idx] += 1
+        g_obs.append(o); g_done.append(d)
+        g_info.append(tuple(x.cpu().numpy().copy() for x in eng.episode_info()))
+    g64 = eng.state_f64().cpu().numpy()
+    assert eng.poll_error() == 0 and used.max() > 10
+    # no two resets share a state: the key is (seed, global env index, global step)
+    first_rows = tape[:2].reshape(-1, 4)
+    assert len(np.unique(first_rows, axis=0)) == len(first_rows)
+
+    ov = oracle.vec(CARTPOLE, n, F_TIME_LIMIT | F_MONITOR, 500)
+    ov.set_reset_tape(tape[:int(used.max())])
+    assert np.array_equal(ov.reset(), obs0)
+    for t in range(T):
+        r = ov.step(acts[t], want64=(t == T - 1))
+        d = r["done"] != 0
+        assert np.array_equal(g_done[t], d), f"done stream diverged at step {t}"
+        assert rel_err(g_obs[t], r["obs"]).max() <= REL, t
+        ln, tr, ret = g_info[t]
+        assert np.array_equal(tr[d], r["truncated"][d]) and np.array_equal(ln[d].astype(np.float32), r["ep_l"][d]) and np.array_equal(ret[d], r["ep_r"][d])
+    assert np.abs(g64 - r["obs64"]).max() <= 1e-12 and (g64 == r["obs64"]).mean() >= 0.999
