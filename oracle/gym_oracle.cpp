@@ -307,6 +307,7 @@ struct RunningMeanStd {
 struct VecNormalize {
     VecEnv* venv; RunningMeanStd obs_rms, ret_rms; std::vector<float> returns, old_obs;
     float clip_obs, clip_rew, gamma, eps;
+    bool training = true, norm_reward = true, norm_obs = true;   // template<bool dict, bool isTraining, bool normReward, bool normObs> (:20)
     VecNormalize(VecEnv* v, float co, float cr, float g, float e)
         : venv(v), obs_rms(v->F), ret_rms(1), returns(v->n(), 0.f), old_obs(v->n() * v->F), clip_obs(co), clip_rew(cr), gamma(g), eps(e) {}
     static float clipf(float v, float lo, float hi) { return std::min(std::max(v, lo), hi); }  // torch::clip
@@ -321,18 +322,24 @@ struct VecNormalize {
     void reset(float* obs) {  // :145-157
         venv->reset(obs, nullptr);
         std::fill(returns.begin(), returns.end(), 0.f);
-        obs_rms.update(obs, venv->n());
-        normalize_obs(obs);
+        if (training && norm_obs) obs_rms.update(obs, venv->n());                // :149-151
+        if (norm_obs) normalize_obs(obs);                                        // :153-155
+        else std::memcpy(old_obs.data(), obs, sizeof(float) * venv->n() * venv->F);
     }
     void step(const int32_t* act, float* obs, float* rew, float* done, uint8_t* trunc, float* ep_r, float* ep_l) {  // :159-177
         int64_t n = venv->n();
         venv->step(act, obs, nullptr, rew, done, trunc, ep_r, ep_l);
-        obs_rms.update(obs, n);                                                  // :162-164
-        normalize_obs(obs);                                                      // :166-167
-        for (int64_t i = 0; i < n; i++) returns[i] = returns[i] * gamma + rew[i];  // :131-132
-        ret_rms.update(returns.data(), n);                                       // :133
-        float sd = std::sqrt(ret_rms.var[0] + eps);
-        for (int64_t i = 0; i < n; i++) rew[i] = clipf(rew[i] / sd, -clip_rew, clip_rew);  // :126-129
+        if (training && norm_obs) obs_rms.update(obs, n);                        // :162-164
+        if (norm_obs) normalize_obs(obs);                                        // :166-167
+        else std::memcpy(old_obs.data(), obs, sizeof(float) * n * venv->F);
+        if (training && norm_reward) {                                           // :169-170
+            for (int64_t i = 0; i < n; i++) returns[i] = returns[i] * gamma + rew[i];  // :131-132
+            ret_rms.update(returns.data(), n);                                   // :133
+        }
+        if (norm_reward) {                                                       // :172-173
+            float sd = std::sqrt(ret_rms.var[0] + eps);
+            for (int64_t i = 0; i < n; i++) rew[i] = clipf(rew[i] / sd, -clip_rew, clip_rew);  // :126-129
+        }
         for (int64_t i = 0; i < n; i++) if (done[i] != 0.f) returns[i] = 0.f;    // :175
     }
 };
@@ -477,6 +484,15 @@ double oracle_vec_rollout(void* p, const uint8_t* tape, int64_t T, float* obs /*
 // VecNormalize on top of the vec env.
 void oracle_vecnorm_attach(void* p, float clip_obs, float clip_rew, float gamma, float eps) {
     auto* h = (OracleVec*)p; h->norm = std::make_unique<VecNormalize>(&h->v, clip_obs, clip_rew, gamma, eps);
+}
+// the class template's flags (vec_normalize.h:20) and a loaded checkpoint (:97-108)
+void oracle_vecnorm_set_flags(void* p, int training, int norm_reward, int norm_obs) {
+    auto* h = (OracleVec*)p; h->norm->training = training; h->norm->norm_reward = norm_reward; h->norm->norm_obs = norm_obs;
+}
+void oracle_vecnorm_set_stats(void* p, const float* in) {
+    auto* h = (OracleVec*)p; int F = h->v.F; auto& n = *h->norm;
+    for (int f = 0; f < F; f++) { n.obs_rms.mean[f] = in[f]; n.obs_rms.var[f] = in[F + f]; }
+    n.obs_rms.count = in[2 * F]; n.ret_rms.mean[0] = in[2 * F + 1]; n.ret_rms.var[0] = in[2 * F + 2]; n.ret_rms.count = in[2 * F + 3];
 }
 void oracle_vecnorm_reset(void* p, float* obs, float* raw_obs) {
     auto* h = (OracleVec*)p; h->norm->reset(obs);

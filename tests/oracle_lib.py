@@ -54,6 +54,8 @@ class Oracle:
         l.oracle_vec_rollout.restype = C.c_double
         l.oracle_vec_rollout.argtypes = [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]
         l.oracle_vecnorm_attach.argtypes = [_vp, _f, _f, _f, _f]
+        l.oracle_vecnorm_set_flags.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
+        l.oracle_vecnorm_set_stats.argtypes = [_vp, _vp]
         l.oracle_vecnorm_reset.argtypes = [_vp, _vp, _vp]
         l.oracle_vecnorm_step.argtypes = [_vp] + [_vp] * 8
         l.oracle_vecnorm_stats.argtypes = [_vp, _vp]
@@ -215,6 +217,12 @@ class OracleVec:
     def attach_norm(self, clip_obs=10.0, clip_rew=10.0, gamma=0.99, eps=1e-8):
         self.lib.oracle_vecnorm_attach(self.h, clip_obs, clip_rew, gamma, eps)
         self.has_norm = True
+
+    def norm_flags(self, training=True, norm_reward=True, norm_obs=True):
+        self.lib.oracle_vecnorm_set_flags(self.h, int(training), int(norm_reward), int(norm_obs))
+
+    def norm_set_stats(self, stats):
+        self.lib.oracle_vecnorm_set_stats(self.h, _p(np.ascontiguousarray(stats, np.float32)))
 
     def norm_reset(self):
         obs = np.empty((self.n, self.F), np.float32)

@@ -239,3 +239,52 @@ def test_update_pushes_rollout_rows_into_the_statistics(oracle):
         assert got[2 * F] == obs_st[2 * F] and got[2 * F + 3] == ret_st[2]                          # counts are exact
     eng.step(torch.zeros(n, dtype=torch.int32, device="cuda"))                                      # and the engine steps on
     assert np.array_equal(eng.norm_stats.cpu().numpy(), eng.get_norm_stats())
+
+
+@pytest.mark.parametrize("training,norm_reward,norm_obs", [(True, True, False), (True, False, True), (False, True, True),
+                                                            (False, True, False), (False, False, True)])
+@pytest.mark.parametrize("kind", ["cartpole", "mountaincar"])
+def test_vecnormalize_template_flag_combinations(oracle, kind, training, norm_reward, norm_obs):
+    """VecNormalize<dict, isTraining, normReward, normObs> (vec_normalize.h:20, 145-177): each `if constexpr` arm on its
+    own — statistics only move for the arms that are both trained and normalised, the other outputs pass through — with
+    non-default clip / gamma / epsilon and statistics loaded from a checkpoint for the frozen cases."""
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+    cart = kind == "cartpole"
+    n, T, F = 3000, 150, 4 if cart else 2
+    clip_obs, clip_rew, gamma, eps = 2.5, 1.5, 0.9, 1e-4
+    w = L.WRAP_TIME_LIMIT | L.WRAP_MONITOR | (0 if cart else L.WRAP_CLIP_REWARD)
+    w |= (L.WRAP_NORM_TRAINING if training else 0) | (L.WRAP_NORM_REWARD if norm_reward else 0) | (L.WRAP_NORM_OBS if norm_obs else 0)
+    eng = Engine(EngineConfig(env_kind=L.ENV_CARTPOLE if cart else L.ENV_MOUNTAINCAR, n_envs=n, precision=L.PRECISION_LOCKSTEP_F64,
+                              reset_mode=L.RESET_TAPE, wrappers=w, max_episode_steps=60, clip_obs=clip_obs, clip_reward=clip_rew,
+                              gamma=gamma, epsilon=eps), 0)
+    ov = oracle.vec(CARTPOLE if cart else MOUNTAINCAR, n, F_TIME_LIMIT | F_MONITOR | (0 if cart else F_CLIP_REWARD), 60)
+    if cart:
+        ov.seed(21)
+        eng.upload_reset_tape(oracle.cartpole_reset_tape(21, n, T // 8 + 4))
+    ov.attach_norm(clip_obs, clip_rew, gamma, eps)
+    ov.norm_flags(training, norm_reward, norm_obs)
+    loaded = np.concatenate([np.linspace(-0.3, 0.2, F), np.linspace(0.02, 0.3, F), [5000.0], [0.7, 2.5, 5000.0]]).astype(np.float32)
+    eng.set_norm_stats(loaded)
+    ov.norm_set_stats(loaded)
+    eng.reset()
+    o_obs, o_raw = ov.norm_reset()
+    assert np.array_equal(eng.obs.cpu().numpy(), o_raw)
+    acts = splitmix_actions(31, T, n, 2 if cart else 3)
+    dev = torch.from_numpy(acts).cuda()
+    for t in range(T):
+        eng.step(dev[t])
+        r = ov.norm_step(acts[t])
+        st = ov.norm_stats()
+        assert np.array_equal(eng.obs.cpu().numpy(), r["raw_obs"]) and np.array_equal(eng.done.cpu().numpy(), r["done"]), t
+        _check_stats(eng.get_norm_stats(), st, F, f"step {t}")
+        g_obs = (eng.obs_norm if norm_obs else eng.obs).cpu().numpy()
+        _check_normalised(g_obs, r["obs"], eng.reward.cpu().numpy(), r["reward"], st, F, eps, f"step {t}")
+        if not norm_reward:
+            assert np.array_equal(eng.reward.cpu().numpy(), r["reward"])            # raw rewards pass through
+    st = eng.get_norm_stats()
+    if not (training and norm_obs):
+        assert np.array_equal(st[:2 * F + 1], loaded[:2 * F + 1])                   # obs statistics frozen
+    if not (training and norm_reward):
+        assert np.array_equal(st[2 * F + 1:], loaded[2 * F + 1:])                   # return statistics frozen
+    assert eng.poll_error() == 0
