@@ -259,3 +259,40 @@ def test_cartpole_lockstep_counter_rng_resets_replayed_by_oracle(oracle):
         ln, tr, ret = g_info[t]
         assert np.array_equal(tr[d], r["truncated"][d]) and np.array_equal(ln[d].astype(np.float32), r["ep_l"][d]) and np.array_equal(ret[d], r["ep_r"][d])
     assert np.abs(g64 - r["obs64"]).max() <= 1e-12 and (g64 == r["obs64"]).mean() >= 0.999
+
+
+@pytest.mark.parametrize("kind,precision,reset_mode", [("cartpole", "lockstep", "tape"), ("cartpole", "lockstep", "rng"), ("cartpole", "f32", "tape"),
+                                                        ("cartpole", "f32", "rng"), ("mountaincar", "lockstep", "rng"), ("mountaincar", "f32", "rng")])
+def test_rollout_of_k_steps_equals_k_step_calls(kind, precision, reset_mode):
+    """gymhip_rollout(K) is K x gymhip_step with the state held in registers: same obs / state / counter words / episode
+    totals, bit for bit, for both env kinds, both precisions and both reset sources, and its recorded streams equal the
+    per-step outputs.  (The counter-RNG key of step k inside a rollout is the global step it would have had.)"""
+    from gym_amd import _lib as L
+    cart = kind == "cartpole"
+    n, K = 5000, 130
+    w = L.WRAP_TIME_LIMIT | L.WRAP_MONITOR | (0 if cart else L.WRAP_CLIP_REWARD)
+    mk = lambda: make_engine(L.ENV_CARTPOLE if cart else L.ENV_MOUNTAINCAR, n, L.PRECISION_LOCKSTEP_F64 if precision == "lockstep" else L.PRECISION_F32,
+                             w, 40, reset_mode=L.RESET_TAPE if (cart and reset_mode == "tape") else L.RESET_COUNTER_RNG, seed=4)
+    a, b = mk(), mk()
+    for e in (a, b):
+        if cart and reset_mode == "tape":
+            e.generate_reset_tape(K // 8 + 4)
+        e.reset()
+    acts = torch.from_numpy(splitmix_actions(3, 2 * K, n, 2 if cart else 3)).cuda()
+    F = 4 if cart else 2
+    for half in range(2):                                  # two rollouts in a row: the second starts mid-episode
+        tape = acts[half * K:(half + 1) * K].contiguous()
+        rec_done = torch.empty((K, n), dtype=torch.uint8, device="cuda")
+        rec_trunc = torch.empty((K, n), dtype=torch.uint8, device="cuda")
+        rec_rew = torch.empty((K, n), dtype=torch.float32, device="cuda")
+        rec_obs = torch.empty((K, n, F), dtype=torch.float32, device="cuda")
+        a.rollout(tape, rec_done, rec_rew, rec_trunc, rec_obs)
+        for k in range(K):
+            b.step(tape[k])
+            assert torch.equal(rec_obs[k], b.obs) and torch.equal(rec_done[k].float(), b.done) and torch.equal(rec_rew[k], b.reward), (half, k)
+            _, tr, _ = b.episode_info()
+            assert torch.equal(rec_trunc[k], tr), (half, k)
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.counter, b.counter) and torch.equal(a.state_f64(), b.state_f64())
+        assert torch.equal(a.done, b.done) and torch.equal(a.reward, b.reward)
+    assert np.array_equal(a.episode_stats(), b.episode_stats()) and a.episode_stats()[0] > n
+    assert a.poll_error() == 0 and b.poll_error() == 0
