@@ -902,7 +902,12 @@ Layout make_layout(const gymhip_config& c) {
     const bool lock = c.precision == GYMHIP_PRECISION_LOCKSTEP_F64;
     const bool norm = c.wrappers & (GYMHIP_WRAP_NORM_OBS | GYMHIP_WRAP_NORM_REWARD);
     size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
+#ifndef GYMHIP_SKEW
+#define GYMHIP_SKEW 0
+#endif
+    // GYMHIP_SKEW (experiment): stagger the stream bases so that equal env indices of different streams do not land on
+    // the same HBM channel when the stream sizes are powers of two.
+    auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes) + (size_t)GYMHIP_SKEW; return o; };
     L.obs = take(n * F * 4);
     L.state = lock ? take(n * F * 4) : L.obs;   // LOCKSTEP: int32 residual rows (split-double), else the obs rows
     L.obs_norm = (c.wrappers & GYMHIP_WRAP_NORM_OBS) ? take(n * F * 4) : (size_t)-1;
