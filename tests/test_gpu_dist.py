@@ -79,3 +79,45 @@ def test_two_rank_sharded_vecnormalize_matches_single_process_oracle(tmp_path, o
             assert (np.abs(r[k]["reward"][t] - o["reward"][lo:hi]) <= 1e-5 * np.maximum(1.0, np.abs(o["reward"][lo:hi]))).all(), t
         episodes += int(o["done"].sum())
     assert r[0]["episodes"][0] == episodes == n                                    # every env truncates once at step 200
+
+
+def _rccl_worker(rank, port, n, T, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+    from gym_amd.vec_env import allreduce_sum
+    from tests.oracle_lib import splitmix_actions
+    w = L.WRAP_TIME_LIMIT | L.WRAP_CLIP_REWARD | L.WRAP_MONITOR | L.WRAP_NORM_OBS | L.WRAP_NORM_REWARD | L.WRAP_NORM_TRAINING
+    mk = lambda: Engine(EngineConfig(env_kind=L.ENV_MOUNTAINCAR, n_envs=n, precision=L.PRECISION_LOCKSTEP_F64, reset_mode=L.RESET_COUNTER_RNG,
+                                     wrappers=w, max_episode_steps=200), 0)
+    a, b = mk(), mk()
+    a.reset()
+    b.reset_begin(); allreduce_sum(b.moments); b.reset_finish()
+    acts = torch.from_numpy(splitmix_actions(5, T, n, 3)).cuda()
+    same = True
+    for t in range(T):
+        a.step(acts[t])
+        b.step_begin(acts[t]); allreduce_sum(b.moments); b.step_finish()      # exactly bench.py's / HipVecEnv's N>1 call sequence
+        same = same and torch.equal(a.obs_norm, b.obs_norm) and torch.equal(a.reward, b.reward) and np.array_equal(a.get_norm_stats(), b.get_norm_stats())
+    tot = torch.from_numpy(b.episode_stats()).cuda()
+    allreduce_sum(tot)
+    mx = torch.tensor([1.25], dtype=torch.float64, device="cuda")
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)                                   # bench.py's max-over-ranks
+    np.savez(os.path.join(out_dir, "rccl.npz"), same=same, tot=tot.cpu().numpy(), ref=a.episode_stats(), mx=mx.cpu().numpy(),
+             backend=np.array(dist.get_backend()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_single_rank_rccl_allreduce_on_the_moments_buffer(tmp_path):
+    """The N>1 code path on the real backend: a one-rank RCCL communicator (all a 1-GPU box can host — RCCL refuses two
+    ranks on one device) all-reduces the f64 `moments` slice of the workspace in place between *_begin and *_finish, on
+    the launch stream; results must equal the unsplit step bit for bit."""
+    mp.spawn(_rccl_worker, args=(_free_port(), 50000, 60, str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "rccl.npz")
+    assert str(r["backend"]) == "nccl" and bool(r["same"]) and np.array_equal(r["tot"], r["ref"]) and r["mx"][0] == 1.25
