@@ -116,3 +116,19 @@ def test_atari_front_end_matches_the_reference_chain(oracle, tmp_path, life_loss
     assert np.array_equal(final, stack.transpose(0, 3, 1, 2))                       # VecNormAndPermute view of the VecFrameStack
     assert pos == raw.size
     assert eps >= 2 and dones >= eps and (life_dones > 0) == life_loss              # the script exercised the branches
+
+
+@pytest.mark.gpu
+def test_cpp_rccl_allreduce_binding_on_the_moments_buffer():
+    """INTEGRATION.md's sharded-normaliser snippet, compiled without libtorch and run on RCCL itself (one-rank
+    communicator): step_begin -> ncclAllReduce(moments, f64, sum) on the launch stream -> step_finish must equal the
+    unsplit step bit for bit."""
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "rccl_moments_demo")
+    assert os.path.exists(exe), "build tests/cpp first"
+    n, T = 30000, 40
+    r = subprocess.run([exe, str(n), str(T)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    line = [l for l in r.stdout.strip().splitlines() if l.startswith("rccl_identical")][-1]   # RCCL may print banners of its own
+    tag, same, _, steps, _, count = line.split()
+    assert same == "1" and int(steps) == T
+    assert float(count) > n * T                                                               # the statistics moved: (T+1) batches of n rows
