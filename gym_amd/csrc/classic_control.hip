@@ -52,6 +52,7 @@ namespace {
 constexpr int kBlock = GYMHIP_BLOCK;   // 512 and 1024 measured no better
 constexpr int kMaxGrid = 8192;  // upper bound of the grid-stride launch (sizes the per-block partial buffers)
 constexpr int kDefaultGrid = 1024;  // 256 CUs x 4 blocks: best of the 512..8192 sweep (profiles/r01_sweep.txt); GYMHIP_GRID overrides
+constexpr size_t kNtFootprint = (size_t)336 << 20;   // bytes; see gymhip_create
 constexpr int kMaxCols = 16;    // >= 2F+6 for F=4
 
 enum : int { KIND_CARTPOLE = GYMHIP_ENV_CARTPOLE, KIND_MOUNTAINCAR = GYMHIP_ENV_MOUNTAINCAR };
@@ -268,29 +269,26 @@ using f32x4 = float __attribute__((ext_vector_type(4)));
 using f32x2 = float __attribute__((ext_vector_type(2)));
 using i32x4 = int32_t __attribute__((ext_vector_type(4)));
 using i32x2 = int32_t __attribute__((ext_vector_type(2)));
-template <typename V> __device__ inline V ld_stream(const V* ptr) {
-#if GYMHIP_NT
-    return __builtin_nontemporal_load(ptr);
-#else
-    return *ptr;
-#endif
+// NT is a template argument so that the step kernel can pick per launch: non-temporal pays when the engine's footprint is
+// well beyond the Infinity Cache (16.7 M envs: +7 %), and costs when it (nearly) fits (4 M envs: -16 %) — see kNtFootprint.
+constexpr bool kNtDefault = GYMHIP_NT != 0;
+template <bool NT = kNtDefault, typename V> __device__ inline V ld_stream(const V* ptr) {
+    if constexpr (NT) return __builtin_nontemporal_load(ptr);
+    else return *ptr;
 }
-template <typename V> __device__ inline void st_stream(V* ptr, V v) {
-#if GYMHIP_NT
-    __builtin_nontemporal_store(v, ptr);
-#else
-    *ptr = v;
-#endif
+template <bool NT = kNtDefault, typename V> __device__ inline void st_stream(V* ptr, V v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, ptr);
+    else *ptr = v;
 }
 
-__device__ inline void load_obs(const float* obs, int64_t i, float (&s)[4]) { f32x4 v = ld_stream((const f32x4*)obs + i); s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w; }
-__device__ inline void load_obs(const float* obs, int64_t i, float (&s)[2]) { f32x2 v = ld_stream((const f32x2*)obs + i); s[0] = v.x; s[1] = v.y; }
-__device__ inline void store_obs(float* obs, int64_t i, const float (&s)[4]) { f32x4 v = {s[0], s[1], s[2], s[3]}; st_stream((f32x4*)obs + i, v); }
-__device__ inline void store_obs(float* obs, int64_t i, const float (&s)[2]) { f32x2 v = {s[0], s[1]}; st_stream((f32x2*)obs + i, v); }
-__device__ inline void load_i32(const int32_t* a, int64_t i, int32_t (&k)[4]) { i32x4 v = ld_stream((const i32x4*)a + i); k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w; }
-__device__ inline void load_i32(const int32_t* a, int64_t i, int32_t (&k)[2]) { i32x2 v = ld_stream((const i32x2*)a + i); k[0] = v.x; k[1] = v.y; }
-__device__ inline void store_i32(int32_t* a, int64_t i, const int32_t (&k)[4]) { i32x4 v = {k[0], k[1], k[2], k[3]}; st_stream((i32x4*)a + i, v); }
-__device__ inline void store_i32(int32_t* a, int64_t i, const int32_t (&k)[2]) { i32x2 v = {k[0], k[1]}; st_stream((i32x2*)a + i, v); }
+template <bool NT = kNtDefault> __device__ inline void load_obs(const float* obs, int64_t i, float (&s)[4]) { f32x4 v = ld_stream<NT>((const f32x4*)obs + i); s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w; }
+template <bool NT = kNtDefault> __device__ inline void load_obs(const float* obs, int64_t i, float (&s)[2]) { f32x2 v = ld_stream<NT>((const f32x2*)obs + i); s[0] = v.x; s[1] = v.y; }
+template <bool NT = kNtDefault> __device__ inline void store_obs(float* obs, int64_t i, const float (&s)[4]) { f32x4 v = {s[0], s[1], s[2], s[3]}; st_stream<NT>((f32x4*)obs + i, v); }
+template <bool NT = kNtDefault> __device__ inline void store_obs(float* obs, int64_t i, const float (&s)[2]) { f32x2 v = {s[0], s[1]}; st_stream<NT>((f32x2*)obs + i, v); }
+template <bool NT = kNtDefault> __device__ inline void load_i32(const int32_t* a, int64_t i, int32_t (&k)[4]) { i32x4 v = ld_stream<NT>((const i32x4*)a + i); k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w; }
+template <bool NT = kNtDefault> __device__ inline void load_i32(const int32_t* a, int64_t i, int32_t (&k)[2]) { i32x2 v = ld_stream<NT>((const i32x2*)a + i); k[0] = v.x; k[1] = v.y; }
+template <bool NT = kNtDefault> __device__ inline void store_i32(int32_t* a, int64_t i, const int32_t (&k)[4]) { i32x4 v = {k[0], k[1], k[2], k[3]}; st_stream<NT>((i32x4*)a + i, v); }
+template <bool NT = kNtDefault> __device__ inline void store_i32(int32_t* a, int64_t i, const int32_t (&k)[2]) { i32x2 v = {k[0], k[1]}; st_stream<NT>((i32x2*)a + i, v); }
 
 // Split-double state (LOCKSTEP).  A double d is kept as the pair (f, k): f = (float)d — exactly the observation the API
 // returns, so the obs row doubles as the high half of the state — and k = (d - (double)f) * 2^(53 - e_f), e_f = f's
@@ -325,13 +323,13 @@ template <int F> __device__ inline void load_state(const StepBuffers& b, int64_t
     join_state<F>(o, k, s);
 }
 // Stores the residual half; the caller stores o (= the float-rounded state) through store_obs.
-template <int F> __device__ inline void store_state(const StepBuffers& b, int64_t i, const double (&s)[F], const float (&o)[F], int32_t* error_flag) {
+template <int F, bool NT = kNtDefault> __device__ inline void store_state(const StepBuffers& b, int64_t i, const double (&s)[F], const float (&o)[F], int32_t* error_flag) {
     int32_t k[F];
     bool out_of_range = false;
 #pragma unroll
     for (int f = 0; f < F; f++) k[f] = split_residual(s[f], o[f], out_of_range);
     if (out_of_range) atomicOr(error_flag, 4);
-    store_i32((int32_t*)b.state, i, k);
+    store_i32<NT>((int32_t*)b.state, i, k);
 }
 
 // Reset state of env i for episode `ep` (already range-checked).
@@ -414,7 +412,7 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_partials_kernel(const d
 // ------------------------------------------------------------------------------------------------------------
 // Kernel A: one VecEnv::step for every env.
 // ------------------------------------------------------------------------------------------------------------
-template <int KIND, bool LOCKSTEP, typename ActT, bool NORM>
+template <int KIND, bool LOCKSTEP, typename ActT, bool NORM, bool NT>
 __global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
     constexpr int F = EnvTraits<KIND>::F;
     using T = typename std::conditional<LOCKSTEP, double, float>::type;
@@ -448,11 +446,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
     // `i` must be a valid env index: the loads are unconditional so that the compiler can count them (a lane with no
     // next iteration re-reads its own, cached, inputs and discards them).
     auto issue_loads = [&](int64_t i, Inputs& in) {
-        load_obs(b.obs, i, in.o);
-        if constexpr (LOCKSTEP) load_i32((const int32_t*)b.state, i, in.k);
-        in.action = (int)ld_stream(actions + i);
-        in.w = ld_stream(b.counter + i);
-        if constexpr (NORM) in.ret = ret_lane ? ld_stream(b.returns + i) : 0.f;
+        load_obs<NT>(b.obs, i, in.o);
+        if constexpr (LOCKSTEP) load_i32<NT>((const int32_t*)b.state, i, in.k);
+        in.action = (int)ld_stream<NT>(actions + i);
+        in.w = ld_stream<NT>(b.counter + i);
+        if constexpr (NORM) in.ret = ret_lane ? ld_stream<NT>(b.returns + i) : 0.f;
     };
 
     // Software pipeline: iteration k+1's loads are issued before iteration k's arithmetic, so they are in flight under
@@ -510,11 +508,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
         float o[F];
 #pragma unroll
         for (int f = 0; f < F; f++) o[f] = (float)s[f];
-        if constexpr (LOCKSTEP) store_state<F>(b, i, s, o, p.error_flag);
-        store_obs(b.obs, i, o);
-        st_stream(b.counter + i, CounterWord<KIND>::pack(t, cursor, done, trunc));
-        st_stream(b.reward + i, reward);
-        st_stream(b.done + i, done ? 1.f : 0.f);
+        if constexpr (LOCKSTEP) store_state<F, NT>(b, i, s, o, p.error_flag);
+        store_obs<NT>(b.obs, i, o);
+        st_stream<NT>(b.counter + i, CounterWord<KIND>::pack(t, cursor, done, trunc));
+        st_stream<NT>(b.reward + i, reward);
+        st_stream<NT>(b.done + i, done ? 1.f : 0.f);
 
         if constexpr (NORM) {
 #pragma unroll
@@ -523,7 +521,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
                 float r = cur.ret * p.gamma + reward;              // vec_normalize.h:132
                 double d = (double)r - (double)shift[F];
                 acc[2 * F] += d; acc[2 * F + 1] += d * d;
-                st_stream(b.returns + i, done ? 0.f : r);         // vec_normalize.h:175 (applied after the RMS update)
+                st_stream<NT>(b.returns + i, done ? 0.f : r);     // vec_normalize.h:175 (applied after the RMS update)
             }
         }
 #if GYMHIP_PIPE
@@ -945,6 +943,7 @@ struct gymhip_engine {
     bool pending_finish;     // a *_begin with the normaliser on awaits its *_finish
     bool pending_is_reset;
     int64_t step_counter;    // VecEnv steps taken so far (COUNTER_RNG reset key)
+    bool stream_nt;          // step kernel streams with non-temporal accesses (footprint beyond the Infinity Cache)
 
     template <typename T> T* at(size_t off) const { return off == (size_t)-1 ? nullptr : (T*)(ws + off); }
     float* stats_slot_ptr(int s) const { return at<float>(L.stats) + 16 * s; }
@@ -991,18 +990,23 @@ int check_handle(gymhip_engine* h) {
     return GYMHIP_OK;
 }
 
-template <int KIND, bool LOCKSTEP, bool NORM>
+template <int KIND, bool LOCKSTEP, bool NORM, bool NT>
 void launch_step_act(gymhip_engine* h, const StepParams& p, int action_dtype, hipStream_t s) {
     switch (action_dtype) {
-        case GYMHIP_ACT_I32: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, int32_t, NORM>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
-        case GYMHIP_ACT_I64: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, int64_t, NORM>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
-        default: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, uint8_t, NORM>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
+        case GYMHIP_ACT_I32: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, int32_t, NORM, NT>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
+        case GYMHIP_ACT_I64: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, int64_t, NORM, NT>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
+        default: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, uint8_t, NORM, NT>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
     }
+}
+template <int KIND, bool LOCKSTEP, bool NORM>
+void launch_step_nt(gymhip_engine* h, const StepParams& p, int action_dtype, hipStream_t s) {
+    if (h->stream_nt) launch_step_act<KIND, LOCKSTEP, NORM, true>(h, p, action_dtype, s);
+    else launch_step_act<KIND, LOCKSTEP, NORM, false>(h, p, action_dtype, s);
 }
 template <int KIND, bool LOCKSTEP>
 void launch_step_norm(gymhip_engine* h, const StepParams& p, int action_dtype, hipStream_t s) {
-    if (h->norm) launch_step_act<KIND, LOCKSTEP, true>(h, p, action_dtype, s);
-    else launch_step_act<KIND, LOCKSTEP, false>(h, p, action_dtype, s);
+    if (h->norm) launch_step_nt<KIND, LOCKSTEP, true>(h, p, action_dtype, s);
+    else launch_step_nt<KIND, LOCKSTEP, false>(h, p, action_dtype, s);
 }
 template <int KIND>
 void launch_step_kind(gymhip_engine* h, const StepParams& p, int action_dtype, hipStream_t s) {
@@ -1082,6 +1086,9 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
     h->tape = nullptr; h->tape_episodes = 0;
     h->did_reset = false; h->pending_finish = false; h->pending_is_reset = false;
     h->step_counter = 0;
+    // Non-temporal streaming pays only once the per-step footprint (workspace + an int32 action row) no longer fits the
+    // 256 MiB Infinity Cache; measured crossover on MI355X between 302 MB (temporal +14 %) and 403 MB (non-temporal +6 %).
+    h->stream_nt = kNtDefault && h->L.total + (size_t)cfg->n_envs * 4 > kNtFootprint;
     if (workspace) {
         if (workspace_bytes < h->L.total || ((uintptr_t)workspace & 255)) { delete h; return fail(GYMHIP_EINVAL, "workspace too small (%zu < %zu) or not 256-B aligned", workspace_bytes, h->L.total); }
         h->ws = (char*)workspace; h->owns_ws = false;
