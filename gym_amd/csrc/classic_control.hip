@@ -606,7 +606,7 @@ __device__ inline void rms_update(float& mean, float& var, float count, float bm
 // Kernel B: apply the (all-reduced) batch moments to the running statistics, then normalise (vec_normalize.h:118-129).
 // Every block derives the new statistics redundantly (identical instructions on identical inputs); block 0 publishes
 // them into the other ping-pong slot, which only the NEXT launches read.
-template <int F>
+template <int F, bool NT>
 __global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
     float mean[F], var[F];
 #pragma unroll
@@ -656,10 +656,10 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
         const int64_t nv = q.n / E;
         for (int64_t j = tid; j < nv; j += nthr) {
             float o[4];
-            load_obs(q.obs, j, o);
+            load_obs<NT>(q.obs, j, o);
 #pragma unroll
             for (int c = 0; c < 4; c++) o[c] = fminf(fmaxf((o[c] - mean[c % F]) / inv_sd[c % F], -q.clip_obs), q.clip_obs);
-            store_obs(q.obs_norm, j, o);
+            store_obs<NT>(q.obs_norm, j, o);
         }
         for (int64_t i = nv * E + tid; i < q.n; i += nthr) {      // F = 2, odd n: the last env
 #pragma unroll
@@ -670,10 +670,10 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
         const int64_t nv = q.n / 4;
         for (int64_t j = tid; j < nv; j += nthr) {
             float r[4];
-            load_obs(q.reward, j, r);
+            load_obs<NT>(q.reward, j, r);
 #pragma unroll
             for (int c = 0; c < 4; c++) r[c] = fminf(fmaxf(r[c] / rsd, -q.clip_reward), q.clip_reward);
-            store_obs(q.reward, j, r);
+            store_obs<NT>(q.reward, j, r);
         }
         for (int64_t i = nv * 4 + tid; i < q.n; i += nthr) q.reward[i] = fminf(fmaxf(q.reward[i] / rsd, -q.clip_reward), q.clip_reward);
     }
@@ -1048,8 +1048,13 @@ int launch_normalize(gymhip_engine* h, bool is_reset, hipStream_t s) {
     q.norm_reward = !is_reset && (w & GYMHIP_WRAP_NORM_REWARD);
     q.update_obs = training && (w & GYMHIP_WRAP_NORM_OBS);                       // vec_normalize.h:149-151,162-164
     q.update_ret = !is_reset && training && (w & GYMHIP_WRAP_NORM_REWARD);       // vec_normalize.h:169-170
-    if (h->F == 4) hipLaunchKernelGGL(normalize_kernel<4>, dim3(h->grid), dim3(kBlock), 0, s, q);
-    else hipLaunchKernelGGL(normalize_kernel<2>, dim3(h->grid), dim3(kBlock), 0, s, q);
+    if (h->F == 4) {
+        if (h->stream_nt) hipLaunchKernelGGL((normalize_kernel<4, true>), dim3(h->grid), dim3(kBlock), 0, s, q);
+        else hipLaunchKernelGGL((normalize_kernel<4, false>), dim3(h->grid), dim3(kBlock), 0, s, q);
+    } else {
+        if (h->stream_nt) hipLaunchKernelGGL((normalize_kernel<2, true>), dim3(h->grid), dim3(kBlock), 0, s, q);
+        else hipLaunchKernelGGL((normalize_kernel<2, false>), dim3(h->grid), dim3(kBlock), 0, s, q);
+    }
     h->stats_slot ^= 1;  // the kernel always publishes the (possibly unchanged) statistics into the other slot
     return GYMHIP_OK;
 }
@@ -1402,8 +1407,8 @@ int gymhip_update_norm_stats(gymhip_engine* h, const float* obs_rows, int64_t n_
         q.moments = h->at<double>(h->L.moments);
         q.clip_obs = h->cfg.clip_obs; q.clip_reward = h->cfg.clip_reward; q.epsilon = h->cfg.epsilon;
         q.update_obs = is_obs; q.update_ret = !is_obs;
-        if (F == 4) hipLaunchKernelGGL(normalize_kernel<4>, dim3(1), dim3(kBlock), 0, s, q);
-        else hipLaunchKernelGGL(normalize_kernel<2>, dim3(1), dim3(kBlock), 0, s, q);
+        if (F == 4) hipLaunchKernelGGL((normalize_kernel<4, false>), dim3(1), dim3(kBlock), 0, s, q);
+        else hipLaunchKernelGGL((normalize_kernel<2, false>), dim3(1), dim3(kBlock), 0, s, q);
         h->stats_slot ^= 1;
         HIP_TRY(hipGetLastError());
         return GYMHIP_OK;

@@ -17,7 +17,7 @@ N4 = 4096           # config 4 envs
 # kernel-name needle -> (key, algorithmic read bytes, algorithmic write bytes) per launch
 KERNELS = {
     "step_kernel<1, true, int, true,": ("config3_step_kernel_mountaincar_lockstep_norm", N3 * (8 + 8 + 4 + 4 + 4), N3 * (8 + 8 + 4 + 4 + 4 + 4)),
-    "normalize_kernel<2>": ("config3_normalize_kernel", N3 * (8 + 4), N3 * (8 + 4)),
+    "normalize_kernel<2,": ("config3_normalize_kernel", N3 * (8 + 4), N3 * (8 + 4)),
     "atari_preprocess_kernel": ("config4_atari_preprocess_rgb", N4 * 2 * 100800, N4 * 7056),
     "materialize_nchw_f32_kernel": ("config4_materialize_nchw_f32", N4 * 28224, N4 * 28224 * 4),
 }
