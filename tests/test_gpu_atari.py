@@ -121,8 +121,9 @@ def test_frame_stack_ring_matches_shift_semantics(oracle):
         assert np.array_equal(pp.stacked_nchw_f32().cpu().numpy(), oracle.norm_permute(stack)), t
 
 
-@pytest.mark.parametrize("k", [1, 3])
+@pytest.mark.parametrize("k", [1, 3, 8])
 def test_frame_stack_other_depths(oracle, k):
+    """k = 8 is the depth the reference's own Atari test stacks (test/atari_env.cpp:50-51: VecFrameStack(..., 8))."""
     from gym_amd.atari import AtariPreprocessor
     n = 4
     pp = AtariPreprocessor(n, n_stack=k)
@@ -130,7 +131,7 @@ def test_frame_stack_other_depths(oracle, k):
     f0 = counter_frames(2, n, 0)
     pp.reset(torch.from_numpy(f0).cuda())
     oracle.framestack_reset(stack, oracle.atari_preprocess(f0))
-    for t in range(1, 5):
+    for t in range(1, 2 * k + 3):
         f = counter_frames(2, n, t)
         pp.step(torch.from_numpy(f).cuda())
         oracle.framestack_update(stack, oracle.atari_preprocess(f))
