@@ -318,6 +318,15 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms_mat = e0.elapsed_time(e1) / steps
+        out16 = torch.empty((n4, 4, 84, 84), dtype=torch.bfloat16, device="cuda")
+        pp.stacked_nchw_16(torch.bfloat16, out16)
+        e0.record()
+        for _ in range(steps):
+            pp.stacked_nchw_16(torch.bfloat16, out16)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_mat16 = e0.elapsed_time(e1) / steps
+        del out16
         # the same step fed with the emulator's palette-index screens (1 B/pixel) and the in-kernel colour table
         pal = torch.randint(0, 1 << 24, (256,), dtype=torch.int64, generator=torch.Generator().manual_seed(3)).numpy().astype("uint32")
         pp.set_palette(pal)
@@ -339,6 +348,7 @@ def main():
                 "achieved_GBs": round(bps * n4 / (ms * 1e-3) / 1e9, 1), "frac": round(bps * n4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "indexed_screens": {"value": n4 / (ms_idx * 1e-3), "kernel_ms": round(ms_idx, 4), "bytes_per_env_step": bps_idx,
                                     "achieved_GBs": round(bps_idx * n4 / (ms_idx * 1e-3) / 1e9, 1)},
+                "materialize_nchw_bf16_ms": round(ms_mat16, 4),
                 "materialize_nchw_f32_ms": round(ms_mat, 4),
                 "materialize_GBs": round((4 * 7056 + 4 * 4 * 7056) * n4 / (ms_mat * 1e-3) / 1e9, 1)}
 

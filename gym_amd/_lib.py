@@ -17,6 +17,7 @@ RESET_TAPE, RESET_COUNTER_RNG = 0, 1
 WRAP_TIME_LIMIT, WRAP_CLIP_REWARD, WRAP_MONITOR = 1, 2, 4
 WRAP_NORM_OBS, WRAP_NORM_REWARD, WRAP_NORM_TRAINING = 8, 16, 32
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
+OUT_F16, OUT_BF16 = 0, 1
 
 
 class GymhipError(RuntimeError):
@@ -115,6 +116,7 @@ SIGNATURES = {
     "gymhip_atari_step_indexed": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gymhip_atari_materialize_nhwc": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_materialize_nchw_f32": (C.c_int, [_vp, _vp, _vp]),
+    "gymhip_atari_materialize_nchw_16": (C.c_int, [_vp, _vp, C.c_int, _vp]),
 }
 
 _lib = None

@@ -101,6 +101,18 @@ class AtariPreprocessor:
         L.check(self.lib.gymhip_atari_materialize_nchw_f32(self.h, C.c_void_p(out.data_ptr()), self._stream()), "gymhip_atari_materialize_nchw_f32")
         return out
 
+    def stacked_nchw_16(self, dtype: torch.dtype = torch.bfloat16, out: torch.Tensor | None = None) -> torch.Tensor:
+        """The same observation rounded once to float16 / bfloat16 [N, k, 84, 84] for half-precision policies."""
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("dtype must be torch.float16 or torch.bfloat16")
+        if out is None:
+            out = torch.empty((self.n, self.k, *self.dst_hw), dtype=dtype, device=self.device)
+        if out.dtype != dtype or not out.is_contiguous() or out.numel() != self.n * self.k * self.dst_hw[0] * self.dst_hw[1]:
+            raise ValueError("out must be a contiguous [N, k, H, W] tensor of the requested dtype")
+        code = L.OUT_F16 if dtype == torch.float16 else L.OUT_BF16
+        L.check(self.lib.gymhip_atari_materialize_nchw_16(self.h, C.c_void_p(out.data_ptr()), code, self._stream()), "gymhip_atari_materialize_nchw_16")
+        return out
+
 
 def host_env_post_step(reward, done, lives, state: dict, clip_reward: bool = True):
     """Fused Monitor -> EpisodicLife -> ClipReward lanes for host-emulated envs (gymhip_host_env_post_step).

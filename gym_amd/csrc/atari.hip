@@ -15,6 +15,7 @@
 //
 // -ffp-contract=off (Makefile) keeps the resampler's mul/add separate, as OpenCV's baseline x86-64 build does.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 
 #include <algorithm>
 #include <cmath>
@@ -284,6 +285,33 @@ __global__ __launch_bounds__(kBlock) void materialize_nchw_f32_kernel(const uint
     }
 }
 
+// The same view in a 16-bit float type for half-precision policies: x / 255 computed in float32 exactly as above, then rounded
+// once, to nearest even, to IEEE half (BF16 = 0) or bfloat16 (BF16 = 1).  8 pixels (16 B out) per thread when P allows.
+template <int BF16> __device__ inline uint32_t to16(float v) {
+    if (BF16) { const uint32_t u = __float_as_uint(v); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; }   // finite, non-negative input
+    return (uint32_t)__half_as_ushort(__float2half_rn(v));
+}
+template <int BF16, int VEC>
+__global__ __launch_bounds__(kBlock) void materialize_nchw_16_kernel(const uint8_t* ring, uint16_t* out, int64_t n, int P, int k, int head) {
+    const int PV = P / VEC;
+    const int64_t total = n * (int64_t)k * PV;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < total; j += (int64_t)gridDim.x * kBlock) {
+        const int64_t ec = j / PV; const int q = (int)(j - ec * PV);
+        const int64_t e = ec / k; const int c = (int)(ec - e * k);
+        const uint32_t* src = (const uint32_t*)(ring + (e * k + ((head + 1 + c) % k)) * (int64_t)P) + q * (VEC / 4);
+        uint32_t o[VEC / 2];
+#pragma unroll
+        for (int v = 0; v < VEC / 4; v++) {
+            const uint32_t w = src[v];
+            o[2 * v] = to16<BF16>((float)(w & 255u) / 255.f) | (to16<BF16>((float)((w >> 8) & 255u) / 255.f) << 16);
+            o[2 * v + 1] = to16<BF16>((float)((w >> 16) & 255u) / 255.f) | (to16<BF16>((float)(w >> 24) / 255.f) << 16);
+        }
+        uint32_t* dst = (uint32_t*)out + j * (VEC / 2);
+#pragma unroll
+        for (int v = 0; v < VEC / 2; v++) dst[v] = o[v];
+    }
+}
+
 // Monitor -> EpisodicLife -> ClipReward over caller lanes, order of AtariWrapper::make (atari_wrappers.cpp:95-121).
 __global__ __launch_bounds__(kBlock) void host_env_post_step_kernel(int64_t n, const float* rew_in, const uint8_t* done_in, const int32_t* lives_in,
                                                                     int32_t* st_lives, uint8_t* st_wrd, float* st_ret, float* st_len, int clip,
@@ -500,6 +528,25 @@ int gymhip_atari_materialize_nchw_f32(gymhip_atari* h, float* out, void* stream)
     const int P = h->cfg.dst_h * h->cfg.dst_w;
     // grid 2048 grid-stride: a one-block-per-tile launch (112,896 blocks) measured 6 % slower
     hipLaunchKernelGGL(materialize_nchw_f32_kernel, dim3(2048), dim3(kBlock), 0, (hipStream_t)stream, h->ring, out, h->cfg.n_envs, P, h->cfg.n_stack, h->head);
+    HIP_TRY(hipGetLastError());
+    return GYMHIP_OK;
+}
+
+int gymhip_atari_materialize_nchw_16(gymhip_atari* h, void* out, int dtype, void* stream) {
+    if (int rc = check_atari(h)) return rc;
+    if (!out) return fail(GYMHIP_EINVAL, "out is null");
+    if (dtype != GYMHIP_OUT_F16 && dtype != GYMHIP_OUT_BF16) return fail(GYMHIP_EINVAL, "dtype must be GYMHIP_OUT_F16 or GYMHIP_OUT_BF16");
+    const int P = h->cfg.dst_h * h->cfg.dst_w;
+    hipStream_t s = (hipStream_t)stream;
+    uint16_t* o = (uint16_t*)out;
+    const int64_t n = h->cfg.n_envs; const int k = h->cfg.n_stack, head = h->head;
+    if (P % 8 == 0) {
+        if (dtype == GYMHIP_OUT_BF16) hipLaunchKernelGGL((materialize_nchw_16_kernel<1, 8>), dim3(2048), dim3(kBlock), 0, s, h->ring, o, n, P, k, head);
+        else hipLaunchKernelGGL((materialize_nchw_16_kernel<0, 8>), dim3(2048), dim3(kBlock), 0, s, h->ring, o, n, P, k, head);
+    } else {
+        if (dtype == GYMHIP_OUT_BF16) hipLaunchKernelGGL((materialize_nchw_16_kernel<1, 4>), dim3(2048), dim3(kBlock), 0, s, h->ring, o, n, P, k, head);
+        else hipLaunchKernelGGL((materialize_nchw_16_kernel<0, 4>), dim3(2048), dim3(kBlock), 0, s, h->ring, o, n, P, k, head);
+    }
     HIP_TRY(hipGetLastError());
     return GYMHIP_OK;
 }

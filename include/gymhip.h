@@ -231,6 +231,11 @@ int gymhip_atari_step_indexed(gymhip_atari* h, const uint8_t* screens, const uin
 int gymhip_atari_materialize_nhwc(gymhip_atari* h, uint8_t* out, void* stream);
 /* VecNormAndPermute::observation fused onto the ring (vec_atari.cpp:70-81): f32 [n_envs][n_stack][dst_h][dst_w] = x / 255. */
 int gymhip_atari_materialize_nchw_f32(gymhip_atari* h, float* out, void* stream);
+/* The same tensor for half-precision policies: x / 255 in float32 as vec_atari.cpp:74-76 computes it,
+ * rounded once (to nearest even) to IEEE half or bfloat16; `out` is 16-bit [n_envs][n_stack][dst_h][dst_w].  Half the
+ * bytes of the float32 view; the reference itself only produces float32. */
+enum { GYMHIP_OUT_F16 = 0, GYMHIP_OUT_BF16 = 1 };
+int gymhip_atari_materialize_nchw_16(gymhip_atari* h, void* out, int dtype, void* stream);
 
 /* Monitor -> EpisodicLifeEnv -> ClipRewardEnv for host-emulated envs, in AtariWrapper::make's order
  * (atari_wrappers.cpp:95-121), over device lanes of n envs.  Inputs per env: the MaxAndSkip-summed reward, the

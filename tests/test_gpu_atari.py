@@ -220,3 +220,32 @@ def test_atari_errors():
         pp.step(torch.zeros((4, 2, H, W, 3), dtype=torch.uint8, device="cuda"))
     with pytest.raises(ValueError):
         pp.preprocess(torch.zeros((4, 2, H, W, 4), dtype=torch.uint8, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("k", [4, 3])
+def test_nchw_16_bit_views_round_the_f32_view_once(oracle, dtype, k):
+    """gymhip_atari_materialize_nchw_16: x / 255 in float32 (vec_atari.cpp:74-76, the oracle's norm_permute), rounded once to
+    nearest-even half / bfloat16 — bit-exact against that rounding of the oracle's tensor; every byte value is covered."""
+    from gym_amd.atari import AtariPreprocessor
+    n = 5
+    pp = AtariPreprocessor(n, n_stack=k)
+    stack = np.zeros((n, 84, 84, k), np.uint8)
+    f0 = counter_frames(3, n, 0)
+    pp.reset(torch.from_numpy(f0).cuda())
+    oracle.framestack_reset(stack, oracle.atari_preprocess(f0))
+    rows = np.arange(210)
+    for t in range(1, k + 3):
+        f = counter_frames(3, n, t)
+        if t >= 3:   # gray bands, a different ramp per env and step: together they put every byte value 0..255 into the ring
+            v = ((rows[None, :] * 5 // 4 + 51 * np.arange(n)[:, None] + 17 * t) % 256).astype(np.uint8)
+            f = np.broadcast_to(v[:, None, :, None, None], (n, 2, 210, 160, 3)).copy()
+        pp.step(torch.from_numpy(f).cuda())
+        oracle.framestack_update(stack, oracle.atari_preprocess(f))
+    want = torch.from_numpy(oracle.norm_permute(stack)).to(dtype)          # torch rounds f32 -> f16 / bf16 to nearest even
+    got = pp.stacked_nchw_16(dtype).cpu()
+    assert got.dtype == dtype and got.shape == (n, k, 84, 84)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert len(np.unique(stack)) >= 200                                     # the frames exercise (nearly) every byte value
+    with pytest.raises(ValueError):
+        pp.stacked_nchw_16(torch.float32)
