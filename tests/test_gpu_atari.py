@@ -249,3 +249,22 @@ def test_nchw_16_bit_views_round_the_f32_view_once(oracle, dtype, k):
     assert len(np.unique(stack)) >= 200                                     # the frames exercise (nearly) every byte value
     with pytest.raises(ValueError):
         pp.stacked_nchw_16(torch.float32)
+
+
+@pytest.mark.parametrize("src_hw,dst_hw", [((210, 160), (84, 84)), ((250, 160), (84, 84)), ((210, 160), (105, 80)), ((210, 160), (96, 96)),
+                                            ((224, 240), (84, 84)), ((84, 84), (84, 84)), ((100, 64), (42, 32))])
+def test_other_geometries_match_the_oracle(oracle, src_hw, dst_hw):
+    """WarpFrameEnv takes (width, height) arguments (warp_frame.h:22-30); the generic INTER_AREA tables cover any
+    down-scale up to 3x per axis: fractional, integer (2x), identity and mixed scales, bit-exact against the oracle.
+    (At an exact 2x scale OpenCV itself takes its integer fast path, whose SIMD form rounds .5 ties up where the generic
+    path rounds to even: oracle and kernel both follow the generic tables there — within the +-1 LSB contract, and as
+    unpinned against OpenCV as the rest of this row.)"""
+    from gym_amd.atari import AtariPreprocessor
+    n = 3
+    rng = np.random.default_rng(11)
+    f = rng.integers(0, 256, (n, 2, src_hw[0], src_hw[1], 3), dtype=np.uint8)
+    pp = AtariPreprocessor(n, src_hw=src_hw, dst_hw=dst_hw)
+    got = pp.preprocess(torch.from_numpy(f).cuda()).cpu().numpy()
+    want = oracle.atari_preprocess(f, dh=dst_hw[0], dw=dst_hw[1])
+    assert got.shape == want.shape == (n, dst_hw[0], dst_hw[1])
+    assert np.array_equal(got, want)
