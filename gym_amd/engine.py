@@ -95,6 +95,10 @@ class Engine:
         return self.workspace[off:off + numel * esz].view(dtype).view(*shape)
 
     def _stream(self):
+        # the caller's current stream as a raw hipStream_t; the private fast path saves ~1 us per call at launch-bound sizes
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        if raw is not None:
+            return C.c_void_p(raw(self.device.index))
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def close(self):
