@@ -377,7 +377,7 @@ def main():
 
     def make_line():
         return {
-            "metric": "env-steps/sec (whole node), CartPole vec_env", "value": main_m["value"], "unit": "env-steps/s",
+            "metric": f"env-steps/sec (whole node), {'CartPole' if args.env == 'cartpole' else 'MountainCar'} vec_env", "value": main_m["value"], "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_m["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.mode == "lockstep" else "f32",
             "data": "synthetic",
