@@ -1,7 +1,7 @@
 """CPU, world_size 2 over gloo (standing in for RCCL): the sharded normaliser reduction.
 
 Each rank owns half of the envs (gym_amd.vec_env.shard_range), builds the moments payload of its shard
-(gym_amd.moments.local_moments — the numpy mirror of step_kernel + reduce_partials_kernel), all-reduces it with the same
+(tests.moments_mirror.local_moments — the numpy mirror of step_kernel + reduce_partials_kernel), all-reduces it with the same
 torch.distributed call HipVecEnv uses, and applies the float32 update (mirror of normalize_kernel).  The result must
 track the oracle's single-process VecNormalize over ALL envs: running statistics to 1e-5, identical on both ranks, and
 independent of the GPU count."""
@@ -30,7 +30,7 @@ def _worker(rank, world, port, n, T, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from gym_amd import moments as M
+    from tests import moments_mirror as M
     from gym_amd.vec_env import shard_range
     from tests.oracle_lib import MOUNTAINCAR, F_CLIP_REWARD, F_MONITOR, F_TIME_LIMIT, Oracle, splitmix_actions
     o = Oracle()
