@@ -112,6 +112,7 @@ public:
     int64_t nEnvs() const { return n; }
     // VecNormAndPermute(VecFrameStack(...)) observation of the last reset()/step(): device f32 [N][n_stack][dst_h][dst_w], ready on `stream`
     const float* observation() const { return dev_obs; }
+    // the engine behind it, e.g. for gymhip_atari_materialize_nchw_16(preprocessor(), out, GYMHIP_OUT_BF16, stream) when the policy runs in half precision
     gymhip_atari* preprocessor() const { return pp; }
 
     // VecEnv::reset(): every env runs its outermost reset (sync_env.h:66-72 -> ... -> FireResetEnv/EpisodicLifeEnv::reset)
