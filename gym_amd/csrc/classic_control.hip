@@ -413,7 +413,10 @@ __global__ __launch_bounds__(kReduceThreads) void reduce_partials_kernel(const d
 // Kernel A: one VecEnv::step for every env.
 // ------------------------------------------------------------------------------------------------------------
 template <int KIND, bool LOCKSTEP, typename ActT, bool NORM, bool NT>
-__global__ __launch_bounds__(kBlock) void step_kernel(const StepParams p) {
+#ifndef GYMHIP_STEP_WAVES
+#define GYMHIP_STEP_WAVES 1   // experiment knob: min waves per SIMD the step kernel is compiled for (caps its VGPRs)
+#endif
+__global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const StepParams p) {
     constexpr int F = EnvTraits<KIND>::F;
     using T = typename std::conditional<LOCKSTEP, double, float>::type;
     constexpr int NCOL = NORM ? 2 * F + 2 : 1;
