@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "gym/hip_vec_env.h"
+#include "gym/monitor_csv.h"
 
 int main(int argc, char** argv) {
     if (argc != 5 && argc != 6) { std::fprintf(stderr, "usage: %s cartpole|mountaincar n_envs steps norm\n", argv[0]); return 2; }
@@ -31,13 +32,18 @@ int main(int argc, char** argv) {
     if (obs.size(0) != n || obs.size(1) != (cart ? 4 : 2) || obs.scalar_type() != torch::kFloat32) return 4;   // test/classic_control.cpp:85-86
     std::printf("reset %.9e\n", obs.to(torch::kFloat64).sum().item<double>());
     auto idx = torch::arange(n, torch::TensorOptions().dtype(torch::kInt64).device(torch::kCUDA, 0));
+    // Monitor CSV of envs 0 and 3 when a directory is given (checked against the oracle's episode records by the test)
+    std::unique_ptr<gym::MonitorCsvLog> csv;
+    if (argc == 6) csv = std::make_unique<gym::MonitorCsvLog>(std::string(argv[5]) + "/monitor", std::vector<int>{0, 3}, 12345u);
     for (int t = 0; t < steps; t++) {
         auto actions = (idx * 7 + t * 3) % n_act;                       // int64 device tensor, like torch::randint(n, N_env)
         auto r = env->step(actions);
         if (!r.reward.defined() || r.reward.size(0) != n || r.reward.size(1) != 1 || r.done.size(1) != 1) return 5;   // sync_env.h:107-112
         std::printf("step %d %lld %.9e %.9e\n", t, (long long)r.done.sum().item<float>(), r.observation.to(torch::kFloat64).sum().item<double>(),
                     r.reward.to(torch::kFloat64).sum().item<double>());
+        if (csv) csv->log(static_cast<gym::HipVecEnv*>(env.get())->infos());
         if (t == steps - 1) {
+            if (csv) csv->flush();
             auto infos = static_cast<gym::HipVecEnv*>(env.get())->infos();
             int with_ep = 0; double len_sum = 0;
             for (auto& m : infos) if (m.count("episode")) { with_ep++; len_sum += std::any_cast<gym::Result>(m["episode"]).l; }

@@ -45,9 +45,13 @@ def test_cpp_training_loop_matches_oracle(oracle, env, norm, tmp_path):
     obs0 = v.norm_reset()[0] if norm else v.reset()
     assert lines[0][0] == "reset" and np.isclose(float(lines[0][1]), obs0.astype(np.float64).sum(), rtol=1e-6, atol=1e-3)
     idx = np.arange(n, dtype=np.int64)
+    csv_rows = {0: [], 3: []}
     for t in range(steps):
         a = ((idx * 7 + t * 3) % n_act).astype(np.int32)
         r = v.norm_step(a) if norm else v.step(a)
+        for i in csv_rows:
+            if r["done"][i]:
+                csv_rows[i].append((float(r["ep_r"][i]), float(r["ep_l"][i])))
         tag, tt, dones, obs_sum, rew_sum = lines[1 + t]
         assert tag == "step" and int(tt) == t
         assert int(dones) == int(r["done"].sum()), t
@@ -56,6 +60,15 @@ def test_cpp_training_loop_matches_oracle(oracle, env, norm, tmp_path):
     d = r["done"] != 0
     assert lines[-1][0] == "infos" and int(lines[-1][1]) == int(d.sum()) and float(lines[-1][2]) == float(r["ep_l"][d].sum())
     if norm:
+        # gym/monitor_csv.h: the reference's per-env Monitor file (monitor.h:20-35) for envs 0 and 3, rows = the oracle's episode records
+        for i, rows in csv_rows.items():
+            text = (tmp_path / "monitor" / f"env{i}.csv").read_text()
+            head = f"t_start: 12345\nid: env{i}\nt,r,l"
+            assert text.startswith(head) and len(rows) >= 1
+            got = [l.split(",") for l in text[len(head):].splitlines()]
+            assert len(got) == len(rows)
+            for (tt, rr, ll), (er, el) in zip(got, rows):
+                assert float(tt) > 0 and rr == "%g" % er and ll == "%g" % el
         st = v.norm_stats()
         F = 2
         om, ov_, oc = load_running_mean_std(str(tmp_path / "observation.pt"))
