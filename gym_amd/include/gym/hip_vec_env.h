@@ -6,6 +6,7 @@
 // Inside the reference tree:   #define GYMHIP_USE_REFERENCE_HEADERS  +  #include "wrappers/vec_env/base.h"  first.
 // Elsewhere the stand-alone mirror in gym/vec_env.h supplies gym::VecEnv<false>.
 #pragma once
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <functional>
@@ -137,6 +138,14 @@ public:
         if (opt.norm_reward) get("returns.pt", &s[2 * F + 1], &s[2 * F + 2], &s[2 * F + 3], 1);
         if (opt.norm_obs) get("observation.pt", &s[0], &s[F], &s[2 * F], F);
         ok(gymhip_set_norm_stats(h, s.data(), opt.stream), "gymhip_set_norm_stats");
+    }
+
+    // Monitor::getEpisodeRewards / getEpisodeLengths in aggregate (monitor.h:104-107): {episodes, sum of returns, sum of
+    // lengths} finished so far on this shard (sum over ranks yourself when sharded).  Synchronises the stream.
+    std::array<double, 3> episodeStatistics() {
+        std::array<double, 3> out{0.0, 0.0, 0.0};
+        if (h) ok(gymhip_episode_stats(h, out.data(), opt.stream), "gymhip_episode_stats");
+        return out;
     }
 
     torch::Tensor oldObs() const { return obs; }                         // vec_normalize.h:94

@@ -48,6 +48,8 @@ int main(int argc, char** argv) {
             int with_ep = 0; double len_sum = 0;
             for (auto& m : infos) if (m.count("episode")) { with_ep++; len_sum += std::any_cast<gym::Result>(m["episode"]).l; }
             std::printf("infos %d %.1f\n", with_ep, len_sum);
+            auto tot = static_cast<gym::HipVecEnv*>(env.get())->episodeStatistics();
+            std::printf("episodes %.0f %.1f %.1f\n", tot[0], tot[1], tot[2]);
         }
     }
     if (argc == 6 && norm) {

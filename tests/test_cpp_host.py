@@ -46,9 +46,12 @@ def test_cpp_training_loop_matches_oracle(oracle, env, norm, tmp_path):
     assert lines[0][0] == "reset" and np.isclose(float(lines[0][1]), obs0.astype(np.float64).sum(), rtol=1e-6, atol=1e-3)
     idx = np.arange(n, dtype=np.int64)
     csv_rows = {0: [], 3: []}
+    tot = np.zeros(3)
     for t in range(steps):
         a = ((idx * 7 + t * 3) % n_act).astype(np.int32)
         r = v.norm_step(a) if norm else v.step(a)
+        dd = r["done"] != 0
+        tot += [dd.sum(), r["ep_r"][dd].astype(np.float64).sum(), r["ep_l"][dd].astype(np.float64).sum()]
         for i in csv_rows:
             if r["done"][i]:
                 csv_rows[i].append((float(r["ep_r"][i]), float(r["ep_l"][i])))
@@ -58,6 +61,8 @@ def test_cpp_training_loop_matches_oracle(oracle, env, norm, tmp_path):
         assert np.isclose(float(obs_sum), r["obs"].astype(np.float64).sum(), rtol=1e-5, atol=2e-2 if norm else 1e-3), t
         assert np.isclose(float(rew_sum), r["reward"].astype(np.float64).sum(), rtol=1e-5, atol=1e-3), t
     d = r["done"] != 0
+    assert lines[-1][0] == "episodes" and [float(x) for x in lines[-1][1:]] == list(tot)   # HipVecEnv::episodeStatistics()
+    lines = lines[:-1]
     assert lines[-1][0] == "infos" and int(lines[-1][1]) == int(d.sum()) and float(lines[-1][2]) == float(r["ep_l"][d].sum())
     if norm:
         # gym/monitor_csv.h: the reference's per-env Monitor file (monitor.h:20-35) for envs 0 and 3, rows = the oracle's episode records
