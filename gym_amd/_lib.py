@@ -18,6 +18,7 @@ WRAP_TIME_LIMIT, WRAP_CLIP_REWARD, WRAP_MONITOR = 1, 2, 4
 WRAP_NORM_OBS, WRAP_NORM_REWARD, WRAP_NORM_TRAINING = 8, 16, 32
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
 OUT_F16, OUT_BF16 = 0, 1
+NOALLOC_MAX_ROWS = 1 << 26
 
 
 class GymhipError(RuntimeError):
@@ -101,6 +102,7 @@ SIGNATURES = {
     "gymhip_poll_error": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_reset_index": (C.c_int, [_vp, _i64, _vp]),
     "gymhip_update_norm_stats": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    "gymhip_update_norm_stats_noalloc": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "gymhip_get_norm_stats": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_set_norm_stats": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_host_env_post_step": (C.c_int, [_i64] + [_vp] * 7 + [C.c_int] + [_vp] * 6),

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <random>
 #include <string>
@@ -929,6 +930,18 @@ Layout make_layout(const gymhip_config& c) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------
+// Static scratch of the allocation-free entry point (gymhip_update_norm_stats_noalloc): the per-block partial sums and the
+// reduced moments that gymhip_update_norm_stats keeps in the engine's workspace.  One copy per GPU, held until the process
+// ends: kNoAllocGrid x kMaxCols partial doubles + kMaxCols moment doubles = 131,200 B.  The array's NAME is only a host-side
+// stand-in; the device address is resolved once per device with hipGetSymbolAddress (resolve_scratch) and every use in
+// host code goes through that pointer.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kNoAllocGrid = kDefaultGrid;                       // blocks of the batch-moments launch == partial rows
+constexpr int64_t kNoAllocMaxRows = (int64_t)1 << 26;             // rows per call (obs rows or reward rows), stated limit
+constexpr size_t kScratchDoubles = (size_t)kNoAllocGrid * kMaxCols + kMaxCols;
+static __device__ __align__(256) double scratch[kScratchDoubles];
+
 struct gymhip_engine {
     gymhip_config cfg;
     int device;
@@ -947,6 +960,7 @@ struct gymhip_engine {
     bool pending_is_reset;
     int64_t step_counter;    // VecEnv steps taken so far (COUNTER_RNG reset key)
     bool stream_nt;          // step kernel streams with non-temporal accesses (footprint beyond the Infinity Cache)
+    double* scratch_dev;     // this device's copy of the static `scratch` array (resolve_scratch)
 
     template <typename T> T* at(size_t off) const { return off == (size_t)-1 ? nullptr : (T*)(ws + off); }
     float* stats_slot_ptr(int s) const { return at<float>(L.stats) + 16 * s; }
@@ -990,6 +1004,25 @@ int check_handle(gymhip_engine* h) {
     if (!h) return fail(GYMHIP_EINVAL, "null engine handle");
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return fail(GYMHIP_EHIP, "hipSetDevice(%d) failed: %s", h->device, hipGetErrorString(e));
+    return GYMHIP_OK;
+}
+
+// Device address of the static `scratch` array on `device` (which must be current).  Each GPU holds its own copy of the
+// array at its own address, so the lookup is done once per device and kept; the array's name itself is never passed to a
+// kernel or a copy.
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+double* g_scratch_dev[kMaxDevices] = {};
+int resolve_scratch(int device, double** out) {
+    if (device < 0 || device >= kMaxDevices) return fail(GYMHIP_EINVAL, "device %d beyond the %d this library keeps scratch pointers for", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_dev[device]) {
+        void* ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) return fail(GYMHIP_EHIP, "hipGetSymbolAddress(scratch) on device %d failed: %s", device, hipGetErrorString(e));
+        g_scratch_dev[device] = (double*)ptr;
+    }
+    *out = g_scratch_dev[device];
     return GYMHIP_OK;
 }
 
@@ -1097,6 +1130,7 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
     // Non-temporal streaming pays only once the per-step footprint (workspace + an int32 action row) no longer fits the
     // 256 MiB Infinity Cache; measured crossover on MI355X between 302 MB (temporal +14 %) and 403 MB (non-temporal +6 %).
     h->stream_nt = kNtDefault && h->L.total + (size_t)cfg->n_envs * 4 > kNtFootprint;
+    if (int rc = resolve_scratch(device, &h->scratch_dev)) { delete h; return rc; }
     if (workspace) {
         if (workspace_bytes < h->L.total || ((uintptr_t)workspace & 255)) { delete h; return fail(GYMHIP_EINVAL, "workspace too small (%zu < %zu) or not 256-B aligned", workspace_bytes, h->L.total); }
         h->ws = (char*)workspace; h->owns_ws = false;
@@ -1387,27 +1421,25 @@ int gymhip_reset_index(gymhip_engine* h, int64_t index, void* stream) {
     return GYMHIP_OK;
 }
 
-int gymhip_update_norm_stats(gymhip_engine* h, const float* obs_rows, int64_t n_obs_rows, const float* reward_rows, int64_t n_reward_rows, void* stream) {
-    if (int rc = check_handle(h)) return rc;
-    if (!h->norm) return fail(GYMHIP_EINVAL, "engine has no normaliser");
-    if (h->pending_finish) return fail(GYMHIP_ESTATE, "previous *_begin has no matching *_finish");
-    if ((obs_rows && n_obs_rows <= 0) || (reward_rows && n_reward_rows <= 0)) return fail(GYMHIP_EINVAL, "row counts must be positive");
-    hipStream_t s = (hipStream_t)stream;
+// Shared body of gymhip_update_norm_stats and its allocation-free variant: `partials` ([>= kDefaultGrid][kMaxCols]) and
+// `moments` ([kMaxCols]) are the only device memory it touches beyond the caller's rows and the engine's statistics.
+static int update_norm_stats_impl(gymhip_engine* h, const float* obs_rows, int64_t n_obs_rows, const float* reward_rows, int64_t n_reward_rows,
+                                  double* partials, double* moments, hipStream_t s) {
     const int F = h->F;
     // one pass per statistic: batch moments -> moments buffer -> RunningMeanStd::updateFromMoment (no normalisation: n = 0 rows)
     auto pass = [&](const float* x, int64_t rows, int width, int stat_off, int col0, int col0_sq, bool is_obs) -> int {
         int64_t g64 = (rows + kBlock - 1) / kBlock;
         const int g = (int)(g64 < kDefaultGrid ? g64 : kDefaultGrid);
-        hipLaunchKernelGGL(batch_moments_kernel, dim3(g), dim3(kBlock), 0, s, x, rows, width, h->stats_slot_ptr(h->stats_slot) + stat_off, col0, col0_sq,
-                           h->at<double>(h->L.partials));
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kReduceThreads), 0, s, h->at<double>(h->L.partials), g, 2 * F + 5, (double)rows,
-                           h->at<double>(h->L.moments));
+        // every launch rewrites all kMaxCols columns of partial rows [0, g) and the reduction reads exactly those rows:
+        // nothing in `partials` has to start at zero, and rows a larger earlier call left behind are never read
+        hipLaunchKernelGGL(batch_moments_kernel, dim3(g), dim3(kBlock), 0, s, x, rows, width, h->stats_slot_ptr(h->stats_slot) + stat_off, col0, col0_sq, partials);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kReduceThreads), 0, s, partials, g, 2 * F + 5, (double)rows, moments);
         NormParams q{};
         q.n = 0;
         q.stats_cur = h->stats_slot_ptr(h->stats_slot);
         q.stats_next = h->stats_slot_ptr(h->stats_slot ^ 1);
         q.stats_public = h->stats_slot_ptr(2);
-        q.moments = h->at<double>(h->L.moments);
+        q.moments = moments;
         q.clip_obs = h->cfg.clip_obs; q.clip_reward = h->cfg.clip_reward; q.epsilon = h->cfg.epsilon;
         q.update_obs = is_obs; q.update_ret = !is_obs;
         if (F == 4) hipLaunchKernelGGL((normalize_kernel<4, false>), dim3(1), dim3(kBlock), 0, s, q);
@@ -1421,6 +1453,31 @@ int gymhip_update_norm_stats(gymhip_engine* h, const float* obs_rows, int64_t n_
     if (reward_rows && (h->cfg.wrappers & GYMHIP_WRAP_NORM_REWARD))
         if (int rc = pass(reward_rows, n_reward_rows, 1, 2 * F + 1, 2 * F, 2 * F + 1, false)) return rc;   // m_RetRMS->update (vec_normalize.h:203-205)
     return GYMHIP_OK;
+}
+
+static int update_norm_stats_checks(gymhip_engine* h, const float* obs_rows, int64_t n_obs_rows, const float* reward_rows, int64_t n_reward_rows) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->norm) return fail(GYMHIP_EINVAL, "engine has no normaliser");
+    if (h->pending_finish) return fail(GYMHIP_ESTATE, "previous *_begin has no matching *_finish");
+    if ((obs_rows && n_obs_rows <= 0) || (reward_rows && n_reward_rows <= 0)) return fail(GYMHIP_EINVAL, "row counts must be positive");
+    return GYMHIP_OK;
+}
+
+int gymhip_update_norm_stats(gymhip_engine* h, const float* obs_rows, int64_t n_obs_rows, const float* reward_rows, int64_t n_reward_rows, void* stream) {
+    if (int rc = update_norm_stats_checks(h, obs_rows, n_obs_rows, reward_rows, n_reward_rows)) return rc;
+    return update_norm_stats_impl(h, obs_rows, n_obs_rows, reward_rows, n_reward_rows, h->at<double>(h->L.partials), h->at<double>(h->L.moments), (hipStream_t)stream);
+}
+
+// The allocation-free variant: same kernels, same order, same results; partial sums and moments live in this GPU's copy of
+// the static `scratch` array instead of the engine's workspace.  No hipMalloc / hipFree / allocating routine on this path.
+int gymhip_update_norm_stats_noalloc(gymhip_engine* h, const float* obs_rows, int64_t n_obs_rows, const float* reward_rows, int64_t n_reward_rows, void* stream) {
+    if (int rc = update_norm_stats_checks(h, obs_rows, n_obs_rows, reward_rows, n_reward_rows)) return rc;
+    if ((obs_rows && n_obs_rows > kNoAllocMaxRows) || (reward_rows && n_reward_rows > kNoAllocMaxRows))
+        return fail(GYMHIP_EINVAL, "gymhip_update_norm_stats_noalloc takes at most %lld rows per call (got %lld obs rows, %lld reward rows)",
+                    (long long)kNoAllocMaxRows, (long long)(obs_rows ? n_obs_rows : 0), (long long)(reward_rows ? n_reward_rows : 0));
+    double* sc = h->scratch_dev;   // resolved for this engine's device in gymhip_create
+    if (!sc) return fail(GYMHIP_ESTATE, "static scratch was not resolved for device %d", h->device);
+    return update_norm_stats_impl(h, obs_rows, n_obs_rows, reward_rows, n_reward_rows, sc, sc + (size_t)kNoAllocGrid * kMaxCols, (hipStream_t)stream);
 }
 
 int gymhip_get_norm_stats(gymhip_engine* h, float* host_out, void* stream) {

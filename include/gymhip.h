@@ -177,6 +177,17 @@ int gymhip_reset_index(gymhip_engine* h, int64_t index, void* stream);
 int gymhip_update_norm_stats(gymhip_engine* h, const float* obs_rows, int64_t n_obs_rows, const float* reward_rows, int64_t n_reward_rows,
                              void* stream);
 
+/* gymhip_update_norm_stats for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arguments, same kernels and bit-identical
+ * results; the per-block partial sums and the reduced moments go through a static 131,200-byte device array that every GPU
+ * the library runs on holds until the process ends, instead of the engine's workspace, and the call performs no
+ * hipMalloc / hipFree / allocating library routine.  Limits: at most GYMHIP_NOALLOC_MAX_ROWS rows per pointer per call
+ * (GYMHIP_EINVAL beyond).  All engines on one GPU share that GPU's array: calls that overlap on one GPU (different streams
+ * or host threads) race — serialise them. */
+#define GYMHIP_NOALLOC_MAX_ROWS (1ll << 26)
+int gymhip_update_norm_stats_noalloc(gymhip_engine* h, const float* obs_rows, int64_t n_obs_rows, const float* reward_rows,
+                                     int64_t n_reward_rows, void* stream);
+
 /* VecNormalize::save/load state (vec_normalize.h:79-108; running_mean_std.h:28-40) as 2F+4 floats, host side. */
 int gymhip_get_norm_stats(gymhip_engine* h, float* host_out, void* stream);
 int gymhip_set_norm_stats(gymhip_engine* h, const float* host_in, void* stream);
