@@ -13,6 +13,11 @@ One JSON line on stdout (rank 0).  `value` counts env-steps of ALL ranks / max-o
 in HBM.  `roofline` prices the step kernel: algorithmic bytes per env-step x envs per launch / mean launch duration
 (HIP events on the launch stream).  `cpu_baseline` is the CPU oracle (a port of the reference's per-env-object
 SyncVecEnv loop) timed on this box's host cores on a bounded sample.
+
+Launch forms: `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) starts N rank processes ITSELF — the
+parent never touches the GPU, relays rank 0's JSON line and exits non-zero if any rank fails or the launch times out —
+and `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the driver's form) runs as the rank it is told
+to be.  Either way there is one process per GPU and `config.ranks_seen` reports the world size torch.distributed saw.
 """
 import argparse
 import json
@@ -43,8 +48,35 @@ def max_over_ranks(torch, dist, dt):
     return float(t.item())
 
 
-def time_engine(torch, dist, eng, actions, steps, warmup, world):
-    """W untimed + K timed VecEnv steps.  Returns (wall seconds max over ranks, mean kernel ms from HIP events)."""
+PREWARM_SECONDS = 0.3   # untimed, before the caller's --warmup: clocks ramp on wall time, not on a step count
+
+
+def prewarm(torch, eng, actions, max_steps=None, seconds=PREWARM_SECONDS):
+    """Untimed pre-warm of fixed WALL time so that the timed region does not depend on the caller's --warmup count for
+    ramped clocks: `seconds` of eng.step (at most `max_steps` of them when the engine's reset tape is finite, the rest of
+    the time on a plain HBM copy loop).  Returns the number of engine steps taken."""
+    t0, k = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds and (max_steps is None or k < max_steps):
+        for _ in range(8):
+            if max_steps is not None and k >= max_steps:
+                break
+            eng.step(actions[k % len(actions)])
+            k += 1
+        torch.cuda.synchronize()
+    if time.perf_counter() - t0 < seconds:
+        a = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+        b = torch.empty_like(a)
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(8):
+                b.copy_(a)
+            torch.cuda.synchronize()
+        del a, b
+    return k
+
+
+def time_engine(torch, dist, eng, actions, steps, warmup, world, prewarm_max_steps=None):
+    """Pre-warm, W untimed + K timed VecEnv steps.  Returns (wall seconds max over ranks, mean kernel ms from HIP events)."""
+    prewarm(torch, eng, actions, prewarm_max_steps)
     for w in range(warmup):
         eng.step(actions[w % len(actions)])
     torch.cuda.synchronize()
@@ -68,25 +100,122 @@ def time_engine(torch, dist, eng, actions, steps, warmup, world):
     return dt, kern_ms
 
 
-def cpu_baseline(n_envs, seconds_target):
-    """CPU oracle (port of the reference's SyncVecEnv loop over per-env wrapper objects), bounded sample."""
+def cpu_baseline(seconds_target):
+    """CPU oracle (port of the reference's per-env-object loop), bounded samples — BASELINE.md's CPU-baseline plan:
+    (0) configs[0] exactly: ONE CartPole env, seed 0, TimeLimit(500), action tape a_t = mt19937(1)() & 1, 5e6 steps, 1 core
+        (loop shape of test/classic_control.cpp:57-63), its done stream checked against the committed golden prefix;
+    (1) the SyncVecEnv-shaped loop (sync_env.h:114-123) at N = 1028 (the reference's own smoke-test size,
+        test/classic_control.cpp:91-97) and N = 65,536 (configs[1]) on 1 core, and OpenMP over envs (the ASyncVecEnv shape,
+        async_env.h:48-86) on all cores the box gives this job."""
     import numpy as np
     from tests.oracle_lib import CARTPOLE, F_MONITOR, F_TIME_LIMIT, Oracle, default_threads, splitmix_actions
     o = Oracle()
-    out = {}
-    for label, threads in (("1", 1), ("all", default_threads())):
-        ov = o.vec(CARTPOLE, n_envs, F_TIME_LIMIT | F_MONITOR, 500, threads=threads)
-        ov.seed(0)
-        ov.reset()
-        T = 250
-        acts = splitmix_actions(99, T, n_envs, 2)
-        done_steps, secs = 0, 0.0
-        while secs < seconds_target:
-            r = ov.rollout(acts, rec_reward=False, rec_done=False, rec_trunc=False)
-            secs += r["seconds"]
-            done_steps += T * n_envs
-        out[label] = (done_steps / secs, threads, done_steps, secs)
+    out = {"nproc_affinity": len(os.sched_getaffinity(0)), "os_cpu_count": os.cpu_count(), "threads_all": default_threads()}
+    # (0) configs[0]
+    T0 = 5_000_000
+    tape = (o.mt19937_raw(1, T0) & 1).astype(np.uint8).reshape(T0, 1)
+    ov = o.vec(CARTPOLE, 1, F_TIME_LIMIT | F_MONITOR, 500, threads=1)
+    ov.seed(0)
+    ov.reset()
+    r = ov.rollout(tape, rec_reward=False, rec_done=True, rec_trunc=False)
+    c0 = {"value": T0 / r["seconds"], "unit": "env-steps/s", "cores": 1, "steps": T0, "seconds": round(r["seconds"], 3),
+          "episodes": int(r["done"].sum())}
+    gpath = os.path.join(ROOT, "tests", "golden", "cartpole_config0_prefix.npz")
+    if os.path.exists(gpath):
+        g = np.load(gpath, allow_pickle=False)
+        k = int(g["steps"])
+        c0["golden_prefix_steps"] = k
+        c0["golden_prefix_ok"] = bool(np.array_equal(np.packbits(r["done"][:k, 0]), g["done"]))
+    out["config0_single_env_5e6_steps"] = c0
+    # (1) vec loops
+    per = max(0.5, seconds_target / 4)
+    for n_envs in (1028, 65536):
+        for label, threads in (("1core", 1), ("allcores", default_threads())):
+            ov = o.vec(CARTPOLE, n_envs, F_TIME_LIMIT | F_MONITOR, 500, threads=threads)
+            ov.seed(0)
+            ov.reset()
+            T = max(8, min(250, (1 << 22) // n_envs))
+            acts = splitmix_actions(99, T, n_envs, 2)
+            done_steps, secs = 0, 0.0
+            while secs < per:
+                rr = ov.rollout(acts, rec_reward=False, rec_done=False, rec_trunc=False)
+                secs += rr["seconds"]
+                done_steps += T * n_envs
+            out[f"vec_{n_envs}_{label}"] = {"value": done_steps / secs, "unit": "env-steps/s", "cores": threads, "env_steps": done_steps,
+                                            "seconds": round(secs, 2)}
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Self-launch: `bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself.
+# ----------------------------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    """Parent of the N rank processes.  It never imports torch and never touches the GPU (the ranks are fresh children, not
+    re-execs of a process that has initialised HIP).  Rank 0's stdout is relayed; the other ranks' stdout goes to stderr.
+    Exit code: 0 only if every rank exited 0; a failing rank's code otherwise; 4 if the launch timed out."""
+    import socket
+    import subprocess
+    import threading
+    n = args.gpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs, lines = [], [[] for _ in range(n)]
+
+    def pump(rank, pipe):
+        for raw in pipe:
+            line = raw.rstrip("\n")
+            lines[rank].append(line)
+            if rank == 0 and not args.launch_dry_run and line.startswith("{"):   # the ONE JSON line; library banners go to stderr
+                print(line, flush=True)
+            else:
+                print(f"[rank {rank}] {line}", file=sys.stderr, flush=True)
+
+    for rank in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GYM_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        p = subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env=env, stdout=subprocess.PIPE, text=True)
+        t = threading.Thread(target=pump, args=(rank, p.stdout), daemon=True)
+        t.start()
+        procs.append((p, t))
+    deadline = time.monotonic() + float(os.environ.get("GYM_BENCH_LAUNCH_TIMEOUT", "1500"))
+    rc, failed_at = 0, None
+    while True:
+        codes = [p.poll() for p, _ in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad and failed_at is None:
+            failed_at = time.monotonic()
+            rc = bad[0][1] if bad[0][1] > 0 else 1
+            print(f"bench.py launcher: rank {bad[0][0]} exited with code {bad[0][1]}", file=sys.stderr, flush=True)
+        if all(c is not None for c in codes):
+            break
+        timed_out = time.monotonic() > deadline
+        # a dead rank leaves the others waiting in a collective: give them a few seconds to print, then end exactly the PIDs we started
+        if timed_out or (failed_at is not None and time.monotonic() - failed_at > 20):
+            if timed_out and rc == 0:
+                rc = 4
+                print("bench.py launcher: timed out waiting for the ranks", file=sys.stderr, flush=True)
+            for p, _ in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.monotonic() + 10
+            for p, _ in procs:
+                try:
+                    p.wait(max(0.1, t_end - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    for _, t in procs:
+        t.join(2)
+    if args.launch_dry_run and rc == 0:
+        ranks = [json.loads(ls[-1]) for ls in lines if ls]
+        ok = sorted(r["rank"] for r in ranks) == list(range(n)) and all(r["world"] == n for r in ranks)
+        print(json.dumps({"launch_dry_run": True, "n_gpus": n, "ranks_seen": len(ranks), "ok": ok, "ranks": sorted(ranks, key=lambda r: r["rank"])}), flush=True)
+        rc = 0 if ok else 5
+    return rc
 
 
 def main():
@@ -102,7 +231,21 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (f32 / MountainCar) measurements")
+    ap.add_argument("--launch-dry-run", action="store_true", help="launcher check: every rank prints its rank/world and exits (no GPU, no torch)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # N > 1 and nobody launched us as a rank: start the N ranks ourselves, BEFORE any torch / GPU call in this process
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if args.launch_dry_run:
+        if os.environ.get("GYM_BENCH_DRY_RUN_FAIL_RANK") == os.environ.get("RANK", "0"):   # launcher test hook: this rank dies
+            sys.exit(7)
+        if os.environ.get("GYM_BENCH_DRY_RUN_HANG_RANK") == os.environ.get("RANK", "0"):   # launcher test hook: this rank never returns
+            time.sleep(3600)
+        print(json.dumps({"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                          "world": int(os.environ.get("WORLD_SIZE", "1")), "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}), flush=True)
+        return
     if os.environ.get("GYM_BENCH_TRACE"):   # debugging aid: dump every thread's stack and exit if the run stalls
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["GYM_BENCH_TRACE"]), exit=True)
@@ -117,6 +260,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running as rank {rank} of {world} (the launcher's world wins)", file=sys.stderr, flush=True)
+    backend = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -133,6 +279,10 @@ def main():
         torch.cuda.set_device(0)
         local_rank = 0
     n = args.envs_per_gpu
+    ranks_seen = dist.get_world_size() if world > 1 else 1
+    if ranks_seen != world:
+        raise RuntimeError(f"torch.distributed reports {ranks_seen} ranks, the environment says {world}")
+    PREWARM_TAPE_STEPS = 64   # engine steps a finite reset tape is sized for beyond W + K (the rest of the pre-warm is a copy loop)
 
     def build(env, mode, reset_mode=None):
         reset_mode = reset_mode or args.reset_mode
@@ -144,7 +294,7 @@ def main():
         eng = Engine(cfg, local_rank)
         if env == "cartpole" and reset_mode == "tape":
             # reset tape rows: every episode lasts >= 8 steps, so (W+K)/8 + 2 rows can never run out
-            eng.generate_reset_tape((args.steps + args.warmup) // 8 + 2)
+            eng.generate_reset_tape((args.steps + args.warmup + PREWARM_TAPE_STEPS) // 8 + 2)
         eng.reset()
         n_act = 2 if env == "cartpole" else 3
         g = torch.Generator(device="cuda").manual_seed(1234 + rank)
@@ -153,7 +303,8 @@ def main():
 
     def measure(env, mode, reset_mode=None):
         eng, acts = build(env, mode, reset_mode)
-        dt, kern_ms = time_engine(torch, dist, eng, acts, args.steps, args.warmup, world)
+        tape_mode = env == "cartpole" and (reset_mode or args.reset_mode) == "tape"
+        dt, kern_ms = time_engine(torch, dist, eng, acts, args.steps, args.warmup, world, PREWARM_TAPE_STEPS if tape_mode else None)
         err = eng.poll_error()
         eps = eng.episode_stats()
         eng.close()
@@ -162,7 +313,7 @@ def main():
         bps = BYTES_PER_STEP[(env, mode)]
         achieved = bps * n / (kern_ms * 1e-3) / 1e9
         return {
-            "value": world * n * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "kernel_ms": kern_ms,
+            "value": world * n * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "kernel_ms": kern_ms, "timed_region_s": dt,
             "achieved_gbs": achieved, "bytes_per_env_step": bps, "error_flag": err, "episodes": eps[0],
         }
 
@@ -189,7 +340,7 @@ def main():
         do_reset()
         g = torch.Generator(device="cuda").manual_seed(77 + rank)
         acts = [torch.randint(0, 3, (n3,), dtype=torch.int32, device="cuda", generator=g) for _ in range(4)]
-        for k in range(10):
+        for k in range(50 if n3 <= (1 << 21) else 10):
             do_step(acts[k % 4])
         torch.cuda.synchronize()
         if world > 1:
@@ -208,8 +359,8 @@ def main():
         eng.close()
         bps = 16 + 16 + 4 + 8 + 8 + 4 + 4 + (8 + 8 + 4 + 4)   # step kernel 60 B + normalise kernel 24 B
         return {"value": world * n3 * steps / dt, "unit": "env-steps/s", "envs_per_gpu": n3, "ms_per_step": round(dt / steps * 1e3, 4),
-                "bytes_per_env_step": bps, "achieved_GBs": round(bps * n3 * steps / dt / 1e9, 1), "collective": "all_reduce(12 x f64)/step" if world > 1 else None,
-                "obs_count": float(stats[4])}
+                "bytes_per_env_step": bps, "achieved_GBs": round(bps * n3 * steps / dt / 1e9, 1), "frac": round(bps * n3 * steps / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "collective": "all_reduce(12 x f64)/step" if world > 1 else None, "obs_count": float(stats[4])}
 
     def measure_config2():
         """BASELINE configs[1]: CartPole N = 65,536, lockstep, tape resets.  (a) one launch per VecEnv::step — 5.5 MB per
@@ -379,11 +530,13 @@ def main():
         return {
             "metric": f"env-steps/sec (whole node), {'CartPole' if args.env == 'cartpole' else 'MountainCar'} vec_env", "value": main_m["value"], "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_m["ms_per_step"],
+            "timed_region_s": round(main_m["timed_region_s"], 6), "prewarm_s": PREWARM_SECONDS,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.mode == "lockstep" else "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.env} vec_env, {n} envs/GPU, TimeLimit+Monitor, fused step+auto-reset ({'in-kernel counter-RNG' if args.reset_mode == 'rng' else 'reset-tape'} resets), {args.mode} arithmetic, "
                                    f"one kernel launch per VecEnv::step (BASELINE configs[4])",
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": f"env-shard x{world}, no data-path collective",
+                       "ranks_seen": ranks_seen, "backend": backend, "launched_by": "bench.py" if os.environ.get("GYM_BENCH_SELF_LAUNCHED") else ("torchrun/env" if world > 1 else "single process"),
                        "error_flag": main_m["error_flag"], "episodes_finished_rank0": main_m["episodes"]},
             "roofline": {"bound": "hbm", "achieved": round(main_m["achieved_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(main_m["achieved_gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -397,16 +550,21 @@ def main():
     # still comes out (and the job ends) if a secondary measurement stalls, e.g. a rank that failed before a collective.
     import threading
 
+    in_flight = ["(none)"]
+
     def on_stall():
-        extra["error"] = "secondary measurements exceeded the time limit; headline unaffected"
+        # the headline line still comes out, but the run is NOT a success: exit non-zero and say what hung
+        extra["error"] = f"secondary measurement {in_flight[0]!r} exceeded the time limit on rank {rank}; headline unaffected"
         emit()
-        os._exit(0)
+        print(f"bench.py: rank {rank} stalled in {in_flight[0]!r}", file=sys.stderr, flush=True)
+        os._exit(3)
 
     dog = threading.Timer(float(os.environ.get("GYM_BENCH_EXTRA_TIMEOUT", "300")), on_stall)
     dog.daemon = True
     dog.start()
 
     def guarded(key, fn, *a):
+        in_flight[0] = key
         try:
             extra[key] = fn(*a)
         except Exception as e:  # noqa: BLE001 — report, never lose the headline line
@@ -425,7 +583,8 @@ def main():
             guarded(f"{env}_{mode}", classic, env, mode)
         guarded(f"cartpole_f32_{other}_resets", classic, "cartpole", "f32", other)
         guarded("config2_cartpole_lockstep_65536", measure_config2)
-        guarded("config3_mountaincar_vecnormalize_1M_per_gpu", measure_config3, 1 << 20, args.steps)
+        guarded("config3_mountaincar_vecnormalize_131072_per_gpu", measure_config3, 1 << 17, max(args.steps, 500))   # configs[2]'s per-GPU shard on 8 GPUs
+        guarded("config3_mountaincar_vecnormalize_1M_per_gpu", measure_config3, 1 << 20, max(args.steps, 200))
         guarded("config3_mountaincar_vecnormalize_16M_per_gpu", measure_config3, 1 << 24, max(20, args.steps // 4))
         if rank == 0:
             guarded("config4_atari_preprocess_4096", measure_atari, 4096, max(20, args.steps // 4))
@@ -433,12 +592,17 @@ def main():
             guarded("pcie_inclusive_never_value", measure_pcie_inclusive, 10)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        in_flight[0] = "cpu_baseline"
         try:
-            c = cpu_baseline(16384, args.cpu_seconds)
-            v, thr, nsteps, secs = c["all"]
-            cpu = {"value": v, "unit": "env-steps/s", "cores": thr, "kind": "port",
-                   "sample": f"CartPole+TimeLimit(500)+Monitor, 16384 envs, {nsteps} env-steps in {secs:.1f}s, OpenMP over envs "
-                             f"(ASyncVecEnv shape); same loop on 1 core: {c['1'][0]:.3e} env-steps/s; os.cpu_count()={os.cpu_count()}"}
+            c = cpu_baseline(args.cpu_seconds)
+            big, c0 = c["vec_65536_allcores"], c["config0_single_env_5e6_steps"]
+            cpu = {"value": big["value"], "unit": "env-steps/s", "cores": big["cores"], "kind": "port",
+                   "sample": f"CartPole+TimeLimit(500)+Monitor, 65536 envs (configs[1]), {big['env_steps']} env-steps in {big['seconds']}s, OpenMP over envs "
+                             f"(ASyncVecEnv shape); 1 core: {c['vec_65536_1core']['value']:.3e}; N=1028: {c['vec_1028_1core']['value']:.3e} (1 core) / "
+                             f"{c['vec_1028_allcores']['value']:.3e} ({c['vec_1028_allcores']['cores']} cores); configs[0] single env 5e6 steps, 1 core: "
+                             f"{c0['value']:.3e} steps/s (golden prefix ok: {c0.get('golden_prefix_ok')}); sched_getaffinity={c['nproc_affinity']}, "
+                             f"os.cpu_count()={c['os_cpu_count']}",
+                   "detail": c}
         except Exception as e:  # noqa: BLE001
             cpu = {"error": f"{type(e).__name__}: {e}"}
 

@@ -103,6 +103,7 @@ SIGNATURES = {
     "gymhip_reset_index": (C.c_int, [_vp, _i64, _vp]),
     "gymhip_update_norm_stats": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "gymhip_update_norm_stats_noalloc": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    "gymhip_diag_pole_sincos": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "gymhip_get_norm_stats": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_set_norm_stats": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_host_env_post_step": (C.c_int, [_i64] + [_vp] * 7 + [C.c_int] + [_vp] * 6),

@@ -869,6 +869,11 @@ __global__ __launch_bounds__(kBlock) void fill_tape_kernel(float4* tape, int64_t
     }
 }
 
+// Diagnostic: the step kernel's own sin/cos of the pole angle, in double, before the float narrowing of cartpole.cpp:39-40.
+__global__ __launch_bounds__(kBlock) void diag_pole_sincos_kernel(const double* __restrict__ theta, int64_t n, double* sn, double* cs) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) pole_sincos(theta[i], &sn[i], &cs[i]);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------------------------------
@@ -1478,6 +1483,14 @@ int gymhip_update_norm_stats_noalloc(gymhip_engine* h, const float* obs_rows, in
     double* sc = h->scratch_dev;   // resolved for this engine's device in gymhip_create
     if (!sc) return fail(GYMHIP_ESTATE, "static scratch was not resolved for device %d", h->device);
     return update_norm_stats_impl(h, obs_rows, n_obs_rows, reward_rows, n_reward_rows, sc, sc + (size_t)kNoAllocGrid * kMaxCols, (hipStream_t)stream);
+}
+
+int gymhip_diag_pole_sincos(const double* theta, int64_t n, double* sin_out, double* cos_out, void* stream) {
+    if (!theta || !sin_out || !cos_out || n <= 0) return fail(GYMHIP_EINVAL, "null pointer or n <= 0");
+    const int64_t g = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(diag_pole_sincos_kernel, dim3((unsigned)(g < kDefaultGrid ? g : kDefaultGrid)), dim3(kBlock), 0, (hipStream_t)stream, theta, n, sin_out, cos_out);
+    HIP_TRY(hipGetLastError());
+    return GYMHIP_OK;
 }
 
 int gymhip_get_norm_stats(gymhip_engine* h, float* host_out, void* stream) {

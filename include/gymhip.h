@@ -188,6 +188,12 @@ int gymhip_update_norm_stats(gymhip_engine* h, const float* obs_rows, int64_t n_
 int gymhip_update_norm_stats_noalloc(gymhip_engine* h, const float* obs_rows, int64_t n_obs_rows, const float* reward_rows,
                                      int64_t n_reward_rows, void* stream);
 
+/* Diagnostic for the parity tests: the sin and cos the CartPole step kernel computes for a pole angle (cartpole.cpp:39-40
+ * calls glibc's double cos/sin and narrows to float; the kernel evaluates the fdlibm polynomials in double and narrows the
+ * same way).  theta / sin_out / cos_out: device f64 [n], values BEFORE the float narrowing, on the current device.
+ * tests/test_sincos_parity.py counts how often the narrowed values differ from glibc's. */
+int gymhip_diag_pole_sincos(const double* theta, int64_t n, double* sin_out, double* cos_out, void* stream);
+
 /* VecNormalize::save/load state (vec_normalize.h:79-108; running_mean_std.h:28-40) as 2F+4 floats, host side. */
 int gymhip_get_norm_stats(gymhip_engine* h, float* host_out, void* stream);
 int gymhip_set_norm_stats(gymhip_engine* h, const float* host_in, void* stream);

@@ -428,6 +428,48 @@ void oracle_mt19937_raw(uint64_t seed, int64_t count, uint32_t* out) {
     for (int64_t i = 0; i < count; i++) out[i] = (uint32_t)g();
 }
 
+// cartpole.cpp:39-40 as the reference's x86-64 build evaluates it: glibc's double cos/sin, narrowed to float.
+void oracle_glibc_sincos_f32(const double* theta, int64_t n, float* sin_out, float* cos_out, int threads) {
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+    for (int64_t i = 0; i < n; i++) { sin_out[i] = (float)std::sin(theta[i]); cos_out[i] = (float)std::cos(theta[i]); }
+}
+
+// Host twin of the HIP kernel's pole_sincos (classic_control.hip in the product tree): the fdlibm k_sin / k_cos polynomials without
+// argument reduction, the same operations in the same order (std::fma == the device's v_fma_f64, both IEEE exact), valid
+// for |x| < 0.3.  It exists so that the ONE arithmetic difference between the device path and the reference — its sin/cos
+// are not glibc's — can be quantified on the CPU over far more angles than a GPU test can carry: how often does
+// float(pole_sincos(theta)) differ from float(glibc(theta))?  (tests/test_sincos_parity.py; a GPU test checks that the
+// device function equals this twin bit for bit.)
+static inline void pole_sincos_twin(double x, double* sn, double* cs) {
+    const double z = x * x;
+    const double rs = std::fma(z, std::fma(z, std::fma(z, std::fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                           -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+    *sn = std::fma(z * x, std::fma(z, rs, -1.66666666666666324348e-01), x);
+    const double rc = z * std::fma(z, std::fma(z, std::fma(z, std::fma(z, std::fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                                            2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    *cs = 1.0 - (0.5 * z - z * rc);
+}
+void oracle_pole_sincos(const double* theta, int64_t n, double* sin_out, double* cos_out, int threads) {
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+    for (int64_t i = 0; i < n; i++) pole_sincos_twin(theta[i], &sin_out[i], &cos_out[i]);
+}
+// Counts, over theta_k = lo + (hi - lo) * (k + 0.5) / count for k in [k0, k0 + count_here) (a dense sweep generated in place, no
+// array), how often the float-rounded twin differs from the float-rounded glibc value: out[0] sin mismatches, out[1] cos
+// mismatches, out[2] largest |twin - glibc| in double ulps of the glibc value (sin), out[3] the same for cos.
+void oracle_sincos_mismatch_sweep(double lo, double hi, int64_t count, int64_t k0, int64_t count_here, double* out, int threads) {
+    int64_t ms = 0, mc = 0; double us = 0, uc = 0;
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static) reduction(+ : ms, mc) reduction(max : us, uc)
+    for (int64_t k = k0; k < k0 + count_here; k++) {
+        const double th = lo + (hi - lo) * (((double)k + 0.5) / (double)count);
+        double s, c; pole_sincos_twin(th, &s, &c);
+        const double gs = std::sin(th), gc = std::cos(th);
+        ms += (float)s != (float)gs; mc += (float)c != (float)gc;
+        const double ulp_s = std::nextafter(std::fabs(gs), INFINITY) - std::fabs(gs), ulp_c = std::nextafter(std::fabs(gc), INFINITY) - std::fabs(gc);
+        us = std::max(us, std::fabs(s - gs) / ulp_s); uc = std::max(uc, std::fabs(c - gc) / ulp_c);
+    }
+    out[0] = (double)ms; out[1] = (double)mc; out[2] = us; out[3] = uc;
+}
+
 void* oracle_vec_create(int kind, int64_t n_envs, int flags, int64_t max_episode_steps, int threads,
                         const float* script_rew, const uint8_t* script_done, int64_t script_len) {
     auto* h = new OracleVec();

@@ -33,6 +33,17 @@ def main():
                         done=np.packbits(r["done"], axis=1), truncated=np.packbits(r["truncated"], axis=1),
                         obs_at=np.array(CHECK_STEPS), obs=r["obs"][CHECK_STEPS], final_obs64=r["final_obs64"],
                         reset_tape=o.cartpole_reset_tape(0, n, 40))
+    # --- BASELINE configs[0]: ONE CartPole env, seed 0, TimeLimit(500), action tape a_t = mt19937(1)() & 1; first 8192 steps --
+    K = 8192
+    tape = (o.mt19937_raw(1, K) & 1).astype(np.uint8).reshape(K, 1)
+    v = o.vec(CARTPOLE, 1, F_TIME_LIMIT | F_MONITOR, 500, threads=1)
+    v.seed(0)
+    obs0 = v.reset()
+    r = v.rollout(tape, rec_obs=True)
+    at = np.array([0, 1, 7, 100, 1000, K - 1])
+    np.savez_compressed(os.path.join(OUT, "cartpole_config0_prefix.npz"), seed=0, action_mt19937_seed=1, steps=K, reset_obs=obs0,
+                        done=np.packbits(r["done"][:, 0]), obs_at=at, obs=r["obs"][at, 0], final_obs64=r["final_obs64"],
+                        episodes=int(r["done"].sum()))
     # --- MountainCar, 64 envs x 450 steps, TimeLimit(200)+ClipReward+Monitor+VecNormalize (config 3 in miniature) --
     n, T = 64, 450
     v = o.vec(MOUNTAINCAR, n, F_TIME_LIMIT | F_CLIP_REWARD | F_MONITOR, 200)

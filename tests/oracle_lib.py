@@ -38,6 +38,9 @@ class Oracle:
         l = self.lib
         l.oracle_cartpole_reset_tape.argtypes = [_u64, _i64, _i64, _i64, _vp, C.c_int]
         l.oracle_mt19937_raw.argtypes = [_u64, _i64, _vp]
+        l.oracle_glibc_sincos_f32.argtypes = [_vp, _i64, _vp, _vp, C.c_int]
+        l.oracle_pole_sincos.argtypes = [_vp, _i64, _vp, _vp, C.c_int]
+        l.oracle_sincos_mismatch_sweep.argtypes = [C.c_double, C.c_double, _i64, _i64, _i64, _vp, C.c_int]
         l.oracle_vec_create.restype = _vp
         l.oracle_vec_create.argtypes = [C.c_int, _i64, C.c_int, _i64, C.c_int, _vp, _vp, _i64]
         l.oracle_vec_destroy.argtypes = [_vp]
@@ -83,6 +86,25 @@ class Oracle:
         out = np.empty(count, np.uint32)
         self.lib.oracle_mt19937_raw(seed, count, _p(out))
         return out
+
+    # ---- sin/cos of the pole angle (cartpole.cpp:39-40) -------------------------------------------------
+    def glibc_sincos_f32(self, theta):
+        theta = np.ascontiguousarray(theta, np.float64)
+        s, c = np.empty(theta.size, np.float32), np.empty(theta.size, np.float32)
+        self.lib.oracle_glibc_sincos_f32(_p(theta), theta.size, _p(s), _p(c), default_threads())
+        return s, c
+
+    def pole_sincos(self, theta):
+        """Host twin of the HIP kernel's pole_sincos (doubles, before the float narrowing)."""
+        theta = np.ascontiguousarray(theta, np.float64)
+        s, c = np.empty(theta.size, np.float64), np.empty(theta.size, np.float64)
+        self.lib.oracle_pole_sincos(_p(theta), theta.size, _p(s), _p(c), default_threads())
+        return s, c
+
+    def sincos_mismatch_sweep(self, lo, hi, count, k0=0, count_here=None):
+        out = np.zeros(4, np.float64)
+        self.lib.oracle_sincos_mismatch_sweep(lo, hi, count, k0, count if count_here is None else count_here, _p(out), default_threads())
+        return dict(sin_mismatches=int(out[0]), cos_mismatches=int(out[1]), sin_max_ulp=float(out[2]), cos_max_ulp=float(out[3]))
 
     def vec(self, kind, n_envs, flags=0, max_episode_steps=0, threads=None, script=None):
         return OracleVec(self, kind, n_envs, flags, max_episode_steps, threads or default_threads(), script)

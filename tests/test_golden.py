@@ -34,6 +34,25 @@ def test_oracle_reproduces_cartpole_golden(oracle):
     assert np.array_equal(g["reset_tape"][0], g["reset_obs"])
 
 
+def _config0_tape(oracle, K):
+    """BASELINE configs[0]'s action tape: a_t = mt19937(1)() & 1."""
+    return (oracle.mt19937_raw(1, K) & 1).astype(np.uint8).reshape(K, 1)
+
+
+def test_oracle_reproduces_config0_prefix_golden(oracle):
+    """BASELINE configs[0] (single env, seed 0, TimeLimit(500), mt19937(1) action tape): first 8192 steps."""
+    g = load("cartpole_config0_prefix.npz")
+    K = int(g["steps"])
+    v = oracle.vec(CARTPOLE, 1, F_TIME_LIMIT | F_MONITOR, 500, threads=1)
+    v.seed(0)
+    assert np.array_equal(v.reset(), g["reset_obs"])
+    r = v.rollout(_config0_tape(oracle, K), rec_obs=True)
+    assert np.array_equal(np.packbits(r["done"][:, 0]), g["done"]) and int(r["done"].sum()) == int(g["episodes"])
+    assert np.array_equal(r["obs"][g["obs_at"], 0], g["obs"]) and np.array_equal(r["final_obs64"], g["final_obs64"])
+    # the survey's probe of the compiled reference: seed 0 resets to (0.0048813522, 0.0092844591, 0.0215189345, 0.0344265737)
+    assert np.allclose(g["reset_obs"][0], [0.0048813522, 0.0092844591, 0.0215189345, 0.0344265737], rtol=0, atol=5e-11)
+
+
 def test_oracle_reproduces_mountaincar_norm_golden(oracle):
     g = load("mountaincar_norm_64x450.npz")
     n, T = 64, 450
@@ -87,8 +106,43 @@ def test_hip_reproduces_cartpole_golden():
         assert np.array_equal(np.packbits(np.stack(done), axis=1), g["done"])
         assert np.array_equal(np.packbits(np.stack(trunc), axis=1), g["truncated"])
         for k, t in enumerate(g["obs_at"]):
-            assert np.allclose(obs[int(t)], g["obs"][k], rtol=1e-5, atol=1e-7)
-        assert np.abs(eng.state_f64().cpu().numpy() - g["final_obs64"]).max() <= 1e-12
+            assert np.array_equal(obs[int(t)], g["obs"][k])
+        assert np.array_equal(eng.state_f64().cpu().numpy(), g["final_obs64"])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_config0_prefix_golden(oracle):
+    """configs[0] on the HIP path: ONE env (a 1-thread grid), library-drawn std::mt19937(0) resets, the 8192-step prefix as
+    one rollout launch and again as 8192 single-step launches (the oracle is used only to draw the mt19937(1) action tape)."""
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+    g = load("cartpole_config0_prefix.npz")
+    K = int(g["steps"])
+    tape = torch.from_numpy(_config0_tape(oracle, K)).cuda()
+    for single_steps in (False, True):
+        eng = Engine(EngineConfig(env_kind=L.ENV_CARTPOLE, n_envs=1, precision=L.PRECISION_LOCKSTEP_F64, reset_mode=L.RESET_TAPE,
+                                  wrappers=L.WRAP_TIME_LIMIT | L.WRAP_MONITOR, max_episode_steps=500), 0)
+        eng.seed_reset_tape(0, K // 8 + 2)
+        eng.reset()
+        assert np.array_equal(eng.obs.cpu().numpy(), g["reset_obs"])
+        if single_steps:
+            done = torch.empty((K, 1), dtype=torch.uint8, device="cuda")
+            obs = {}
+            for t in range(K):
+                eng.step(tape[t])
+                done[t] = eng.done.to(torch.uint8)
+                if t in g["obs_at"]:
+                    obs[t] = eng.obs.cpu().numpy()[0]
+            got_obs = np.stack([obs[int(t)] for t in g["obs_at"]])
+        else:
+            done = torch.empty((K, 1), dtype=torch.uint8, device="cuda")
+            rec = torch.empty((K, 1, 4), dtype=torch.float32, device="cuda")
+            eng.rollout(tape, rec_done=done, rec_obs=rec)
+            got_obs = rec.cpu().numpy()[g["obs_at"], 0]
+        assert np.array_equal(np.packbits(done.cpu().numpy()[:, 0]), g["done"])
+        assert np.array_equal(got_obs, g["obs"])
+        assert np.array_equal(eng.state_f64().cpu().numpy(), g["final_obs64"])
+        assert int(eng.episode_stats()[0]) == int(g["episodes"]) and eng.poll_error() == 0
 
 
 @pytest.mark.gpu

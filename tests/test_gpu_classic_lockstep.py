@@ -14,6 +14,18 @@ pytestmark = pytest.mark.gpu
 REL = 1e-5
 
 
+def assert_mountaincar_obs(got, want, where):
+    """MountainCar's only non-reference arithmetic is the device library's double cos(3*pos) (mountain_car.cpp:19 calls
+    glibc's), used WITHOUT a float narrowing, so the fp64 state may differ in its last bit (measured: <= 8e-16, 0 of 131,072
+    final values after 1000 steps) and a float32 observation lands on the other side of a rounding tie once in ~1e8 values
+    (measured: 1 of 131,072,000; tools/measure_exactness.py).  Bar: bit-identical except at most max(1, 1e-6 x size) values,
+    and those one float ulp apart."""
+    bad = got != want
+    if bad.any():
+        assert bad.sum() <= max(1, int(1e-6 * got.size)), f"{int(bad.sum())} observation values differ at {where}"
+        assert (np.abs(got[bad].view(np.int32) - want[bad].view(np.int32)) <= 1).all(), where
+
+
 def rel_err(a, b):
     return np.abs(a - b) / np.maximum(np.abs(b), 1e-2)   # abs floor 1e-2 as in SURVEY.md §7
 
@@ -61,18 +73,18 @@ def test_cartpole_step_api_lockstep_every_step(oracle):
         g_done = eng.done.cpu().numpy()
         assert np.array_equal(g_done, r["done"]), f"done stream diverged at step {t}"
         assert np.array_equal(eng.reward.cpu().numpy(), r["reward"])
-        assert rel_err(g_obs, r["obs"]).max() <= REL, f"obs diverged at step {t}"
+        assert np.array_equal(g_obs, r["obs"]), f"obs diverged at step {t}: {int((g_obs != r['obs']).sum())} values"
         d = r["done"] != 0
         if d.any():
             n_done += int(d.sum())
             check_episode_info(eng, r, d)
         if t % 250 == 0 or t == T - 1:
-            # the fp64 state itself: bit-exact unless device sin/cos round differently from glibc (then <= 1e-12)
+            # the fp64 state itself is BIT-IDENTICAL to the oracle's: the only arithmetic that is not the reference's own
+            # op sequence is sin/cos, whose float-narrowed values equal glibc's except within ~1 double ulp of a float tie
+            # (tests/test_sincos_parity.py: 0 mismatches in 3.2e10 evaluations), and the split-double store is lossless
             g64 = eng.state_f64().cpu().numpy()                 # [n][4], split-double halves joined on the device
-            assert np.abs(g64 - r["obs64"]).max() <= 1e-12
+            assert np.array_equal(g64, r["obs64"]), f"{int((g64 != r['obs64']).sum())} state values differ at step {t}"
             assert np.array_equal(g64.astype(np.float32), g_obs)   # obs IS the high half of the state
-            # the split-double store is lossless: a lossy one would leave (almost) no value bit-identical to the oracle's
-            assert (g64 == r["obs64"]).mean() >= 0.999
     assert n_done > n * T / 40            # episodes did end (mean length ~22)
     assert eng.poll_error() == 0
     tot = eng.episode_stats()
@@ -104,11 +116,11 @@ def test_cartpole_config2_rollout_65536x10000(oracle):
         assert np.array_equal(rec_done.cpu().numpy(), r["done"]), f"done stream diverged in chunk {c}"
         assert np.array_equal(rec_trunc.cpu().numpy(), r["truncated"]), f"truncated stream diverged in chunk {c}"
         assert np.array_equal(rec_rew.cpu().numpy(), r["reward"])
-        assert rel_err(eng.obs.cpu().numpy(), r["final_obs"]).max() <= REL
+        assert np.array_equal(eng.obs.cpu().numpy(), r["final_obs"]), f"obs diverged in chunk {c}"
+        assert np.array_equal(eng.state_f64().cpu().numpy(), r["final_obs64"]), f"fp64 state diverged in chunk {c}"
         if last:
-            assert rel_err(rec_obs.cpu().numpy(), r["obs"]).max() <= REL
+            assert np.array_equal(rec_obs.cpu().numpy(), r["obs"])
         episodes += int(r["done"].sum())
-    assert np.abs(eng.state_f64().cpu().numpy() - r["final_obs64"]).max() <= 1e-12
     assert eng.poll_error() == 0
     assert eng.episode_stats()[0] == episodes
 
@@ -129,7 +141,7 @@ def test_mountaincar_lockstep(oracle):
         r = ov.step(acts[t])
         assert np.array_equal(eng.done.cpu().numpy(), r["done"]), t
         assert np.array_equal(eng.reward.cpu().numpy(), r["reward"])
-        assert rel_err(eng.obs.cpu().numpy(), r["obs"]).max() <= REL, t
+        assert_mountaincar_obs(eng.obs.cpu().numpy(), r["obs"], t)
         d = r["done"] != 0
         if d.any():
             check_episode_info(eng, r, d)
@@ -156,7 +168,7 @@ def test_mountaincar_goal_reached_directed_policy(oracle):
         if d.any():
             check_episode_info(eng, r, d)
             terminated += int((d & (r["truncated"] == 0)).sum())
-        assert rel_err(eng.obs.cpu().numpy(), obs).max() <= REL
+        assert_mountaincar_obs(eng.obs.cpu().numpy(), obs, t)
     assert terminated > 0
 
 
@@ -182,7 +194,7 @@ def test_cartpole_no_time_limit_uses_internal_500(oracle):
         if d.any():
             lens += list(r["ep_l"][d])
             check_episode_info(eng, r, d)
-        assert rel_err(eng.obs.cpu().numpy(), obs).max() <= REL
+        assert np.array_equal(eng.obs.cpu().numpy(), obs), t
     assert 501.0 in lens
 
 
@@ -219,7 +231,7 @@ def test_cartpole_lockstep_counter_rng_resets_replayed_by_oracle(oracle):
     in-kernel counter hash, so the oracle cannot draw them — it REPLAYS them.  Every reset observation the engine
     produced (exact: a reset state is four floats widened to double) is collected, per env and in order of use, into
     a reset tape, and the oracle re-runs the whole trajectory from it.  done / truncated / episode records bit-exact,
-    obs within 1e-5, the fp64 state at the end within 1e-12."""
+    observations and the fp64 state at the end bit-identical."""
     from gym_amd import _lib as L
     n, T = 4096, 700
     eng = make_engine(L.ENV_CARTPOLE, n, L.PRECISION_LOCKSTEP_F64, L.WRAP_TIME_LIMIT | L.WRAP_MONITOR, 500, reset_mode=L.RESET_COUNTER_RNG, seed=5)
@@ -255,10 +267,10 @@ def test_cartpole_lockstep_counter_rng_resets_replayed_by_oracle(oracle):
         r = ov.step(acts[t], want64=(t == T - 1))
         d = r["done"] != 0
         assert np.array_equal(g_done[t], d), f"done stream diverged at step {t}"
-        assert rel_err(g_obs[t], r["obs"]).max() <= REL, t
+        assert np.array_equal(g_obs[t], r["obs"]), t
         ln, tr, ret = g_info[t]
         assert np.array_equal(tr[d], r["truncated"][d]) and np.array_equal(ln[d].astype(np.float32), r["ep_l"][d]) and np.array_equal(ret[d], r["ep_r"][d])
-    assert np.abs(g64 - r["obs64"]).max() <= 1e-12 and (g64 == r["obs64"]).mean() >= 0.999
+    assert np.array_equal(g64, r["obs64"])
 
 
 @pytest.mark.parametrize("kind,precision,reset_mode", [("cartpole", "lockstep", "tape"), ("cartpole", "lockstep", "rng"), ("cartpole", "f32", "tape"),

@@ -32,9 +32,9 @@ def test_cartpole_lockstep_ragged(oracle, n):
         r = ov.step(acts[t], want64=True)
         assert np.array_equal(eng.done.cpu().numpy(), r["done"]), t
         assert np.array_equal(eng.reward.cpu().numpy(), r["reward"]), t
-        assert np.allclose(eng.obs.cpu().numpy(), r["obs"], rtol=1e-5, atol=1e-7), t
+        assert np.array_equal(eng.obs.cpu().numpy(), r["obs"]), t
         episodes += int(r["done"].sum())
-    assert np.abs(eng.state_f64().cpu().numpy() - r["obs64"]).max() <= 1e-12
+    assert np.array_equal(eng.state_f64().cpu().numpy(), r["obs64"])
     assert eng.episode_stats()[0] == episodes and eng.poll_error() == 0
     # the rollout form from the same point
     tape = splitmix_actions(4, 16, n, 2)
