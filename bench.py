@@ -326,16 +326,20 @@ def main():
                                   wrappers=w, max_episode_steps=200, env_offset=rank * n3), local_rank)
 
         def do_reset():
-            eng.reset_begin()
             if world > 1:
+                eng.reset_begin()
                 allreduce_sum(eng.moments)
-            eng.reset_finish()
+                eng.reset_finish()
+            else:
+                eng.reset()
 
         def do_step(a):
-            eng.step_begin(a)
             if world > 1:
+                eng.step_begin(a)
                 allreduce_sum(eng.moments)
-            eng.step_finish()
+                eng.step_finish()
+            else:
+                eng.step(a)   # single GPU: step kernel + normalise kernel (partial rows folded in its prologue)
 
         do_reset()
         g = torch.Generator(device="cuda").manual_seed(77 + rank)

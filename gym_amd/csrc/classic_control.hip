@@ -48,11 +48,11 @@ using namespace gymhip;
 namespace {
 
 #ifndef GYMHIP_BLOCK
-#define GYMHIP_BLOCK 256
+#define GYMHIP_BLOCK 512
 #endif
-constexpr int kBlock = GYMHIP_BLOCK;   // 512 and 1024 measured no better
+constexpr int kBlock = GYMHIP_BLOCK;   // 512: equal to 256 on the headline kernel, best on the normaliser pair (profiles/r02_sweep_block.txt)
 constexpr int kMaxGrid = 8192;  // upper bound of the grid-stride launch (sizes the per-block partial buffers)
-constexpr int kDefaultGrid = 1024;  // 256 CUs x 4 blocks: best of the 512..8192 sweep (profiles/r01_sweep.txt); GYMHIP_GRID overrides
+constexpr int kDefaultGrid = 512;   // 256 CUs x 2 blocks of 512 threads: best of the sweeps (profiles/r01_sweep.txt, r02_sweep_block.txt); GYMHIP_GRID overrides
 constexpr size_t kNtFootprint = (size_t)336 << 20;   // bytes; see gymhip_create
 constexpr int kMaxCols = 16;    // >= 2F+6 for F=4
 
@@ -355,58 +355,90 @@ __device__ inline void reset_state(const StepParams& p, int64_t i, int64_t ep, T
     }
 }
 
-// Wave/block reduction of per-thread double columns into partials[blockIdx][cols] in a fixed order (deterministic).
+// Block reduction of per-thread double columns in a fixed order (deterministic), through LDS: every thread parks its COLS
+// values column-major, 16 threads per column then sum kBlock/16 consecutive entries each, and thread c < COLS sums the
+// 16 segment totals of column c.  ~COLS LDS stores + kBlock/16 + 16 LDS loads/adds per thread — the earlier shuffle tree
+// (6 levels x COLS 64-bit cross-lane moves) cost about as much as two MountainCar env-steps per thread, which is what a
+// block's epilogue weighed at the 131,072 .. 1 M envs per GPU that BASELINE configs[2] specifies.
+// Returns the column total in threads tid < COLS (0 elsewhere).  Needs 16 * COLS <= kBlock.
+constexpr int kSeg = kBlock / 16;          // entries per segment
+constexpr int kSegPad = kSeg + 1;          // +1 double: the 16 segments of a column start in different LDS banks
 template <int COLS>
-__device__ inline void block_reduce_store(double (&v)[COLS], double* out_row, bool accumulate) {
-    __shared__ double red[kBlock / 64][COLS];
+__device__ inline double block_reduce_cols(const double (&v)[COLS]) {
+    static_assert(16 * COLS <= kBlock, "one 16-thread group per column");
+    __shared__ double red[COLS][16 * kSegPad];
+    __shared__ double seg_tot[COLS][16];
+    const int tid = threadIdx.x;
+    {
+        const int seg = tid / kSeg, k = tid - seg * kSeg;
 #pragma unroll
-    for (int c = 0; c < COLS; c++) {
-        double x = v[c];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        v[c] = x;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int c = 0; c < COLS; c++) red[wave][c] = v[c];
+        for (int c = 0; c < COLS; c++) red[c][seg * kSegPad + k] = v[c];
     }
     __syncthreads();
-    if (threadIdx.x < COLS) {
-        double t = 0;
+    {
+        const int c = tid >> 4, seg = tid & 15;
+        if (c < COLS) {
+            double t = 0;
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; w++) t += red[w][threadIdx.x];
+            for (int k = 0; k < kSeg; k++) t += red[c][seg * kSegPad + k];
+            seg_tot[c][seg] = t;
+        }
+    }
+    __syncthreads();
+    double tot = 0;
+    if (tid < COLS) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) tot += seg_tot[tid][k];
+    }
+    return tot;
+}
+template <int COLS>
+__device__ inline void block_reduce_store(double (&v)[COLS], double* out_row, bool accumulate) {
+    double t = block_reduce_cols<COLS>(v);
+    if (threadIdx.x < COLS) {
         if (accumulate) t += out_row[threadIdx.x];
         out_row[threadIdx.x] = t;
     }
 }
 
-// Kernel F: partials[rows][kMaxCols] -> moments[0] = n_local, moments[1 + c] = column sums.  One 1024-thread block, fixed
-// summation order (64 row groups, four independent accumulators each so the row loads overlap, then 64 -> 1).
-// A separate launch on purpose: folding it into the step kernel ("the block that finishes last reduces") needs a
-// device-scope release/acquire fence per block, and on MI355X each such fence writes back and invalidates an XCD's
-// whole L2 — measured at +80 us per step at 16.7 M envs, against 5 us for this launch.
-constexpr int kReduceThreads = 1024;
-__global__ __launch_bounds__(kReduceThreads) void reduce_partials_kernel(const double* __restrict__ partials, int rows, int cols, double n_local, double* moments) {
-    __shared__ double red[kReduceThreads / 16][kMaxCols];
-    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;  // 64 row groups x 16 columns
-    double t[4] = {0, 0, 0, 0};
-    if (c < cols) {
-        int r = g;
-        for (; r + 3 * 64 < rows; r += 4 * 64) {
+// partials[rows][kMaxCols] -> column totals, by exactly kFoldThreads (256) threads of a block in a fixed order: 16 row groups
+// x 16 columns, four independent accumulators per thread so that the row loads overlap, then 16 -> 1.  Used by the stand-alone
+// reduce kernel (split step: the totals are the all-reduce payload) AND by the normalise kernel's prologue (unsplit step: no
+// separate launch) — one function, one summation order, so the split and the unsplit step agree bit for bit.
+// Thread tid < cols returns the total of column tid.  `red` is LDS [16][kMaxCols].
+constexpr int kFoldThreads = 256;
+static_assert(kBlock >= kFoldThreads, "the normalise kernel's prologue needs 256 threads");
+__device__ inline double fold_partial_rows(const double* __restrict__ partials, int rows, int cols, double (*red)[kMaxCols], int tid) {
+    if (tid < kFoldThreads) {
+        const int c = tid & 15, g = tid >> 4;
+        double t[4] = {0, 0, 0, 0};
+        if (c < cols) {
+            int r = g;
+            for (; r + 3 * 16 < rows; r += 4 * 16) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) t[k] += partials[(int64_t)(r + k * 64) * kMaxCols + c];
+                for (int k = 0; k < 4; k++) t[k] += partials[(int64_t)(r + k * 16) * kMaxCols + c];
+            }
+            for (; r < rows; r += 16) t[0] += partials[(int64_t)r * kMaxCols + c];
         }
-        for (; r < rows; r += 64) t[0] += partials[(int64_t)r * kMaxCols + c];
+        red[g][c] = (t[0] + t[1]) + (t[2] + t[3]);
     }
-    red[g][c] = (t[0] + t[1]) + (t[2] + t[3]);
     __syncthreads();
-    if (threadIdx.x < cols) {
-        double s = 0;
+    double s = 0;
+    if (tid < cols) {
 #pragma unroll
-        for (int k = 0; k < kReduceThreads / 16; k++) s += red[k][threadIdx.x];
-        moments[1 + threadIdx.x] = s;
+        for (int k = 0; k < 16; k++) s += red[k][tid];
     }
+    return s;
+}
+
+// Kernel F (split step only): partials -> moments[0] = n_local, moments[1 + c] = column totals; one block.
+// A separate launch on purpose when an all-reduce sits between step and normalise.  (Folding it into the step kernel — "the
+// block that finishes last reduces" — needs a device-scope release/acquire fence per block, and on MI355X each such fence
+// writes back and invalidates an XCD's whole L2: measured at +80 us per step at 16.7 M envs.)
+__global__ __launch_bounds__(kFoldThreads) void reduce_partials_kernel(const double* __restrict__ partials, int rows, int cols, double n_local, double* moments) {
+    __shared__ double red[16][kMaxCols];
+    const double s = fold_partial_rows(partials, rows, cols, red, threadIdx.x);
+    if ((int)threadIdx.x < cols) moments[1 + threadIdx.x] = s;
     if (threadIdx.x == 0) moments[0] = n_local;
 }
 
@@ -533,15 +565,22 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
 #endif
     }
 
+    // ONE block reduction for the batch-moment columns and the three episode counters; thread c < COLS owns column c.
     if constexpr (NORM) {
         double cols[2 * F + 5];
 #pragma unroll
         for (int c = 0; c < 2 * F + 2; c++) cols[c] = acc[c];
         cols[2 * F + 2] = ep[0]; cols[2 * F + 3] = ep[1]; cols[2 * F + 4] = ep[2];
-        block_reduce_store<2 * F + 5>(cols, p.partials + (int64_t)blockIdx.x * kMaxCols, false);
+        const double t = block_reduce_cols<2 * F + 5>(cols);
+        const int c = threadIdx.x;
+        if (c < 2 * F + 5) {
+            p.partials[(int64_t)blockIdx.x * kMaxCols + c] = t;
+            // cumulative per-block episode counters (owner-block read-modify-write: no atomics, deterministic)
+            if (c >= 2 * F + 2) p.ep_partials[(int64_t)blockIdx.x * 4 + (c - (2 * F + 2))] += t;
+        }
+    } else {
+        block_reduce_store<3>(ep, p.ep_partials + (int64_t)blockIdx.x * 4, true);
     }
-    // cumulative per-block episode counters (owner-block read-modify-write: no atomics, deterministic)
-    block_reduce_store<3>(ep, p.ep_partials + (int64_t)blockIdx.x * 4, true);
 }
 
 // VecEnv::reset(): every env starts a new episode.  In TAPE mode env i takes the tape row at its own cursor and advances it —
@@ -612,17 +651,47 @@ __device__ inline void rms_update(float& mean, float& var, float count, float bm
 // them into the other ping-pong slot, which only the NEXT launches read.
 template <int F, bool NT>
 __global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
+    // A thread's unit of streaming work is a GROUP: F 16-B observation vectors (one from each of F equal chunks of the first
+    // 4 * ng envs' rows) + one 16-B reward vector; ng = n / 4 groups cover exactly the first 4 * ng envs.  The first
+    // group's loads are issued before anything else, so that they are in flight under the statistics prologue below (at the
+    // 131,072 .. 1 M envs per GPU of BASELINE configs[2] the prologue is a third of this kernel's time).
+    struct Group { float o[F][4]; float r[4]; };
+    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x, nthr = (int64_t)gridDim.x * kBlock;
+    const int64_t ng = q.n / 4;
+    auto load_group = [&](int64_t j, Group& g) {
+        if (q.norm_obs) {
+#pragma unroll
+            for (int v = 0; v < F; v++) load_obs<NT>(q.obs, v * ng + j, g.o[v]);   // F chunks of ng vectors: every load instruction is lane-contiguous
+        }
+        if (q.norm_reward) load_obs<NT>(q.reward, j, g.r);
+    };
+    Group cur;
+    if (tid < ng) load_group(tid, cur);
+
     float mean[F], var[F];
 #pragma unroll
     for (int f = 0; f < F; f++) { mean[f] = q.stats_cur[f]; var[f] = q.stats_cur[F + f]; }
     float ocount = q.stats_cur[2 * F], rmean = q.stats_cur[2 * F + 1], rvar = q.stats_cur[2 * F + 2], rcount = q.stats_cur[2 * F + 3];
-    const double n = q.moments[0];
+    // The batch moments: either already reduced (and all-reduced over ranks) in q.moments — the split step — or, for the
+    // unsplit single-GPU step, summed here from the step kernel's per-block partial rows by every block redundantly (the rows
+    // sit in L2; same function and order as reduce_partials_kernel, so both forms give identical bits).  Saves one launch.
+    __shared__ double fold_red[16][kMaxCols];
+    __shared__ double mom[kMaxCols];
+    if (q.partials) {
+        const double tot = fold_partial_rows(q.partials, q.rows, 2 * F + 5, fold_red, threadIdx.x);
+        if ((int)threadIdx.x < 2 * F + 5) { mom[1 + threadIdx.x] = tot; if (blockIdx.x == 0) q.moments_out[1 + threadIdx.x] = tot; }
+        if (threadIdx.x == 0) { mom[0] = q.n_local; if (blockIdx.x == 0) q.moments_out[0] = q.n_local; }
+    } else if ((int)threadIdx.x < 2 * F + 6) {
+        mom[threadIdx.x] = q.moments[threadIdx.x];
+    }
+    __syncthreads();
+    const double n = mom[0];
     const float nf = (float)n;
     if (q.update_obs) {
         const float tot = ocount + nf;
 #pragma unroll
         for (int f = 0; f < F; f++) {
-            double m1 = q.moments[1 + f] / n, m2 = q.moments[1 + F + f] / n;
+            double m1 = mom[1 + f] / n, m2 = mom[1 + F + f] / n;
             double v = m2 - m1 * m1;
             float bm = (float)((double)mean[f] + m1), bv = (float)(v > 0 ? v : 0.0);
             rms_update(mean[f], var[f], ocount, bm, bv, nf, tot);
@@ -631,7 +700,7 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
     }
     if (q.update_ret) {
         const float tot = rcount + nf;
-        double m1 = q.moments[1 + 2 * F] / n, m2 = q.moments[2 + 2 * F] / n;
+        double m1 = mom[1 + 2 * F] / n, m2 = mom[2 + 2 * F] / n;
         double v = m2 - m1 * m1;
         float bm = (float)((double)rmean + m1), bv = (float)(v > 0 ? v : 0.0);
         rms_update(rmean, rvar, rcount, bm, bv, nf, tot);
@@ -646,40 +715,40 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
             o[2 * F] = ocount; o[2 * F + 1] = rmean; o[2 * F + 2] = rvar; o[2 * F + 3] = rcount;
         }
         if (q.ep_totals_global) {
-            q.ep_totals_global[0] += q.moments[2 * F + 3]; q.ep_totals_global[1] += q.moments[2 * F + 4]; q.ep_totals_global[2] += q.moments[2 * F + 5];
+            q.ep_totals_global[0] += mom[2 * F + 3]; q.ep_totals_global[1] += mom[2 * F + 4]; q.ep_totals_global[2] += mom[2 * F + 5];
         }
     }
-    float inv_sd[F];
+    float sd[F];
 #pragma unroll
-    for (int f = 0; f < F; f++) inv_sd[f] = sqrtf(var[f] + q.epsilon);   // divisor, not reciprocal: keep the reference's divide
+    for (int f = 0; f < F; f++) sd[f] = sqrtf(var[f] + q.epsilon);   // divisor, not reciprocal: keep the reference's divide
     const float rsd = sqrtf(rvar + q.epsilon);
-    // Two streaming passes, each 16 B per lane: obs rows (F = 2: two envs per lane), then rewards four envs per lane.
-    const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x, nthr = (int64_t)gridDim.x * kBlock;
-    if (q.norm_obs) {
-        constexpr int E = 4 / F;                      // envs per 16-B vector
-        const int64_t nv = q.n / E;
-        for (int64_t j = tid; j < nv; j += nthr) {
-            float o[4];
-            load_obs<NT>(q.obs, j, o);
+    auto norm_o = [&](float x, int f) { return fminf(fmaxf((x - mean[f]) / sd[f], -q.clip_obs), q.clip_obs); };       // vec_normalize.h:118-124
+    auto norm_r = [&](float x) { return fminf(fmaxf(x / rsd, -q.clip_reward), q.clip_reward); };                      // vec_normalize.h:126-129
+    // One streaming pass, software-pipelined one group ahead.  Element c of an observation vector is feature c % F (4 % F == 0).
+    for (int64_t j = tid; j < ng; j += nthr) {
+        Group nxt;
+        if (j + nthr < ng) load_group(j + nthr, nxt);
+        if (q.norm_obs) {
 #pragma unroll
-            for (int c = 0; c < 4; c++) o[c] = fminf(fmaxf((o[c] - mean[c % F]) / inv_sd[c % F], -q.clip_obs), q.clip_obs);
-            store_obs<NT>(q.obs_norm, j, o);
-        }
-        for (int64_t i = nv * E + tid; i < q.n; i += nthr) {      // F = 2, odd n: the last env
+            for (int v = 0; v < F; v++) {
 #pragma unroll
-            for (int f = 0; f < F; f++) q.obs_norm[i * F + f] = fminf(fmaxf((q.obs[i * F + f] - mean[f]) / inv_sd[f], -q.clip_obs), q.clip_obs);
+                for (int c = 0; c < 4; c++) cur.o[v][c] = norm_o(cur.o[v][c], c % F);
+                store_obs<NT>(q.obs_norm, v * ng + j, cur.o[v]);
+            }
         }
+        if (q.norm_reward) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) cur.r[c] = norm_r(cur.r[c]);
+            store_obs<NT>(q.reward, j, cur.r);
+        }
+        cur = nxt;
     }
-    if (q.norm_reward) {
-        const int64_t nv = q.n / 4;
-        for (int64_t j = tid; j < nv; j += nthr) {
-            float r[4];
-            load_obs<NT>(q.reward, j, r);
+    for (int64_t i = ng * 4 + tid; i < q.n; i += nthr) {               // the last n % 4 envs
+        if (q.norm_obs) {
 #pragma unroll
-            for (int c = 0; c < 4; c++) r[c] = fminf(fmaxf(r[c] / rsd, -q.clip_reward), q.clip_reward);
-            store_obs<NT>(q.reward, j, r);
+            for (int f = 0; f < F; f++) q.obs_norm[i * F + f] = norm_o(q.obs[i * F + f], f);
         }
-        for (int64_t i = nv * 4 + tid; i < q.n; i += nthr) q.reward[i] = fminf(fmaxf(q.reward[i] / rsd, -q.clip_reward), q.clip_reward);
+        if (q.norm_reward) q.reward[i] = norm_r(q.reward[i]);
     }
 }
 
@@ -898,9 +967,13 @@ bool valid_config(const gymhip_config* c) {
 
 int grid_for(int64_t n) {
     int64_t cap = kDefaultGrid;
-    if (const char* e = getenv("GYMHIP_GRID")) { int v = atoi(e); if (v > 0 && v <= kMaxGrid) cap = v; }
-    int64_t g = (n + kBlock - 1) / kBlock;
-    return (int)(g < cap ? g : cap);
+    if (const char* e = getenv("GYMHIP_GRID")) { int v = atoi(e); if (v > 0 && v <= kMaxGrid) return (int)std::min<int64_t>(v, (n + kBlock - 1) / kBlock); }
+    // One env per thread until every CU has a block (256); then up to 8 envs per thread before the grid grows to its cap: at
+    // the 131,072 .. 1 M envs per GPU of BASELINE configs[2] fewer blocks mean fewer partial rows for the normalise kernel to fold.
+    const int64_t one_per_thread = (n + kBlock - 1) / kBlock;
+    if (one_per_thread <= 256) return (int)one_per_thread;
+    const int64_t g = (n + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8);
+    return (int)std::min<int64_t>(cap, std::max<int64_t>(256, g));
 }
 
 Layout make_layout(const gymhip_config& c) {
@@ -942,7 +1015,8 @@ Layout make_layout(const gymhip_config& c) {
 // stand-in; the device address is resolved once per device with hipGetSymbolAddress (resolve_scratch) and every use in
 // host code goes through that pointer.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kNoAllocGrid = kDefaultGrid;                       // blocks of the batch-moments launch == partial rows
+constexpr int kNoAllocGrid = 1024;                               // partial rows the scratch holds (>= the batch-moments launch's blocks)
+static_assert(kNoAllocGrid >= kDefaultGrid, "the batch-moments launch writes one partial row per block");
 constexpr int64_t kNoAllocMaxRows = (int64_t)1 << 26;             // rows per call (obs rows or reward rows), stated limit
 constexpr size_t kScratchDoubles = (size_t)kNoAllocGrid * kMaxCols + kMaxCols;
 static __device__ __align__(256) double scratch[kScratchDoubles];
@@ -1067,11 +1141,11 @@ void launch_reset_kind(gymhip_engine* h, const StepParams& p, hipStream_t s) {
 }
 
 void launch_reduce_partials(gymhip_engine* h, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kReduceThreads), 0, s, h->at<double>(h->L.partials), h->grid, 2 * h->F + 5,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kFoldThreads), 0, s, h->at<double>(h->L.partials), h->grid, 2 * h->F + 5,
                        (double)h->cfg.n_envs, h->at<double>(h->L.moments));
 }
 
-int launch_normalize(gymhip_engine* h, bool is_reset, hipStream_t s) {
+int launch_normalize(gymhip_engine* h, bool is_reset, hipStream_t s, bool fold) {
     const uint32_t w = h->cfg.wrappers;
     const bool training = w & GYMHIP_WRAP_NORM_TRAINING;
     NormParams q{};
@@ -1080,6 +1154,7 @@ int launch_normalize(gymhip_engine* h, bool is_reset, hipStream_t s) {
     q.stats_next = h->stats_slot_ptr(h->stats_slot ^ 1);
     q.stats_public = h->stats_slot_ptr(2);
     q.moments = h->at<double>(h->L.moments);
+    if (fold) { q.partials = h->at<double>(h->L.partials); q.rows = h->grid; q.n_local = (double)h->cfg.n_envs; q.moments_out = h->at<double>(h->L.moments); }
     q.ep_totals_global = is_reset ? nullptr : h->at<double>(h->L.ep_totals_global);
     q.obs = h->at<float>(h->L.obs);
     q.obs_norm = h->at<float>(h->L.obs_norm);
@@ -1278,7 +1353,7 @@ int gymhip_download_reset_tape(gymhip_engine* h, float* host_tape, int64_t episo
     return GYMHIP_OK;
 }
 
-int gymhip_reset_begin(gymhip_engine* h, void* stream) {
+static int reset_begin_impl(gymhip_engine* h, void* stream, bool split) {
     if (int rc = check_handle(h)) return rc;
     if (h->pending_finish) return fail(GYMHIP_ESTATE, "previous *_begin has no matching *_finish");
     if (h->cfg.env_kind == KIND_CARTPOLE && h->cfg.reset_mode == GYMHIP_RESET_TAPE && !h->tape)
@@ -1286,15 +1361,19 @@ int gymhip_reset_begin(gymhip_engine* h, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     StepParams p = make_params(h);
     if (h->cfg.env_kind == KIND_CARTPOLE) launch_reset_kind<KIND_CARTPOLE>(h, p, s); else launch_reset_kind<KIND_MOUNTAINCAR>(h, p, s);
-    if (h->norm) launch_reduce_partials(h, s);
+    if (h->norm) {
+        if (split) launch_reduce_partials(h, s);         // the totals are the all-reduce payload
+        else launch_normalize(h, true, s, true);         // unsplit: the normalise kernel folds the partial rows itself
+    }
     HIP_TRY(hipGetLastError());
     h->did_reset = true;
     h->step_counter += 1;
-    h->pending_finish = h->norm; h->pending_is_reset = true;
+    h->pending_finish = h->norm && split; h->pending_is_reset = true;
     return GYMHIP_OK;
 }
+int gymhip_reset_begin(gymhip_engine* h, void* stream) { return reset_begin_impl(h, stream, true); }
 
-int gymhip_step_begin(gymhip_engine* h, const void* actions, int action_dtype, void* stream) {
+static int step_begin_impl(gymhip_engine* h, const void* actions, int action_dtype, void* stream, bool split) {
     if (int rc = check_handle(h)) return rc;
     if (!actions) return fail(GYMHIP_EINVAL, "actions is null");
     if (action_dtype < GYMHIP_ACT_I32 || action_dtype > GYMHIP_ACT_U8) return fail(GYMHIP_EINVAL, "unknown action_dtype %d", action_dtype);
@@ -1304,18 +1383,22 @@ int gymhip_step_begin(gymhip_engine* h, const void* actions, int action_dtype, v
     StepParams p = make_params(h);
     p.actions = actions;
     if (h->cfg.env_kind == KIND_CARTPOLE) launch_step_kind<KIND_CARTPOLE>(h, p, action_dtype, s); else launch_step_kind<KIND_MOUNTAINCAR>(h, p, action_dtype, s);
-    if (h->norm) launch_reduce_partials(h, s);
+    if (h->norm) {
+        if (split) launch_reduce_partials(h, s);
+        else launch_normalize(h, false, s, true);
+    }
     HIP_TRY(hipGetLastError());
     h->step_counter += 1;
-    h->pending_finish = h->norm; h->pending_is_reset = false;
+    h->pending_finish = h->norm && split; h->pending_is_reset = false;
     return GYMHIP_OK;
 }
+int gymhip_step_begin(gymhip_engine* h, const void* actions, int action_dtype, void* stream) { return step_begin_impl(h, actions, action_dtype, stream, true); }
 
 static int finish_common(gymhip_engine* h, bool is_reset, void* stream) {
     if (int rc = check_handle(h)) return rc;
     if (!h->norm) return GYMHIP_OK;
     if (!h->pending_finish || h->pending_is_reset != is_reset) return fail(GYMHIP_ESTATE, "*_finish without the matching *_begin");
-    launch_normalize(h, is_reset, (hipStream_t)stream);
+    launch_normalize(h, is_reset, (hipStream_t)stream, false);
     HIP_TRY(hipGetLastError());
     h->pending_finish = false;
     return GYMHIP_OK;
@@ -1323,14 +1406,10 @@ static int finish_common(gymhip_engine* h, bool is_reset, void* stream) {
 int gymhip_step_finish(gymhip_engine* h, void* stream) { return finish_common(h, false, stream); }
 int gymhip_reset_finish(gymhip_engine* h, void* stream) { return finish_common(h, true, stream); }
 
-int gymhip_reset(gymhip_engine* h, void* stream) {
-    if (int rc = gymhip_reset_begin(h, stream)) return rc;
-    return gymhip_reset_finish(h, stream);
-}
-int gymhip_step(gymhip_engine* h, const void* actions, int action_dtype, void* stream) {
-    if (int rc = gymhip_step_begin(h, actions, action_dtype, stream)) return rc;
-    return gymhip_step_finish(h, stream);
-}
+// The unsplit forms: two launches with the normaliser on (step/reset, then normalise with the partial-row fold in its
+// prologue), one without; bit-identical to _begin + _finish.
+int gymhip_reset(gymhip_engine* h, void* stream) { return reset_begin_impl(h, stream, false); }
+int gymhip_step(gymhip_engine* h, const void* actions, int action_dtype, void* stream) { return step_begin_impl(h, actions, action_dtype, stream, false); }
 
 int gymhip_rollout(gymhip_engine* h, const uint8_t* action_tape, int64_t k_steps, uint8_t* rec_done, float* rec_reward,
                    uint8_t* rec_truncated, float* rec_obs, void* stream) {
@@ -1438,13 +1517,12 @@ static int update_norm_stats_impl(gymhip_engine* h, const float* obs_rows, int64
         // every launch rewrites all kMaxCols columns of partial rows [0, g) and the reduction reads exactly those rows:
         // nothing in `partials` has to start at zero, and rows a larger earlier call left behind are never read
         hipLaunchKernelGGL(batch_moments_kernel, dim3(g), dim3(kBlock), 0, s, x, rows, width, h->stats_slot_ptr(h->stats_slot) + stat_off, col0, col0_sq, partials);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kReduceThreads), 0, s, partials, g, 2 * F + 5, (double)rows, moments);
         NormParams q{};
         q.n = 0;
         q.stats_cur = h->stats_slot_ptr(h->stats_slot);
         q.stats_next = h->stats_slot_ptr(h->stats_slot ^ 1);
         q.stats_public = h->stats_slot_ptr(2);
-        q.moments = moments;
+        q.partials = partials; q.rows = g; q.n_local = (double)rows; q.moments_out = moments;   // the one-block normalise launch folds the rows itself
         q.clip_obs = h->cfg.clip_obs; q.clip_reward = h->cfg.clip_reward; q.epsilon = h->cfg.epsilon;
         q.update_obs = is_obs; q.update_ret = !is_obs;
         if (F == 4) hipLaunchKernelGGL((normalize_kernel<4, false>), dim3(1), dim3(kBlock), 0, s, q);

@@ -42,7 +42,11 @@ struct NormParams {
     const float* stats_cur;
     float* stats_next;
     float* stats_public;
-    const double* moments;
+    const double* moments;   // reduced batch moments (split step), read when `partials` is null
+    const double* partials;  // unsplit step: the step kernel's per-block rows [rows][16], folded in the kernel's prologue
+    int rows;
+    double n_local;
+    double* moments_out;     // unsplit step: block 0 publishes the folded moments here (the engine's `moments` buffer)
     double* ep_totals_global;
     const float* obs;
     float* obs_norm;

@@ -60,9 +60,11 @@ public:
 
     torch::Tensor reset() noexcept override {   // sync_env.h:66-72 / vec_normalize.h:145-157
         if (!ensure()) return {};
-        if (!ok(gymhip_reset_begin(h, opt.stream), "gymhip_reset_begin")) return {};
-        if (hasNorm() && opt.allreduce) opt.allreduce(buf.moments, (size_t)buf.moments_len, opt.stream);
-        if (!ok(gymhip_reset_finish(h, opt.stream), "gymhip_reset_finish")) return {};
+        if (hasNorm() && opt.allreduce) {   // sharded: batch moments all-reduced between the two halves
+            if (!ok(gymhip_reset_begin(h, opt.stream), "gymhip_reset_begin")) return {};
+            opt.allreduce(buf.moments, (size_t)buf.moments_len, opt.stream);
+            if (!ok(gymhip_reset_finish(h, opt.stream), "gymhip_reset_finish")) return {};
+        } else if (!ok(gymhip_reset(h, opt.stream), "gymhip_reset")) return {};
         return opt.norm_obs ? obs_norm : obs;
     }
 
@@ -80,9 +82,11 @@ public:
         else if (a.is_cuda() && a.is_contiguous() && a.scalar_type() == torch::kUInt8) dt = GYMHIP_ACT_U8;
         else { a = a.to(torch::Device(torch::kCUDA, opt.device), torch::kInt32).contiguous(); dt = GYMHIP_ACT_I32; }
         if (a.numel() != numEnvs) { std::fprintf(stderr, "HipVecEnv: expected %d actions, got %lld\n", numEnvs, (long long)a.numel()); return {}; }
-        if (!ok(gymhip_step_begin(h, a.data_ptr(), dt, opt.stream), "gymhip_step_begin")) return {};
-        if (hasNorm() && opt.allreduce) opt.allreduce(buf.moments, (size_t)buf.moments_len, opt.stream);
-        if (!ok(gymhip_step_finish(h, opt.stream), "gymhip_step_finish")) return {};
+        if (hasNorm() && opt.allreduce) {
+            if (!ok(gymhip_step_begin(h, a.data_ptr(), dt, opt.stream), "gymhip_step_begin")) return {};
+            opt.allreduce(buf.moments, (size_t)buf.moments_len, opt.stream);
+            if (!ok(gymhip_step_finish(h, opt.stream), "gymhip_step_finish")) return {};
+        } else if (!ok(gymhip_step(h, a.data_ptr(), dt, opt.stream), "gymhip_step")) return {};
         pending = torch::Tensor();
         return {opt.norm_obs ? obs_norm : obs, reward.unsqueeze(-1), done.unsqueeze(-1), {}};   // sync_env.h:107-112 shapes
     }

@@ -226,10 +226,12 @@ class HipVecEnv(VecEnv):
             return (e.obs_norm if (self._norm and self._norm["norm_obs"]) else e.obs)[int(index)]
         self._ensure_engine()
         e = self.engine
-        e.reset_begin()
-        if self._has_norm():
+        if self._has_norm() and self.world > 1:   # sharded: the batch moments are all-reduced between the two halves of the call
+            e.reset_begin()
             self._allreduce_moments()
-        e.reset_finish()
+            e.reset_finish()
+        else:
+            e.reset()
         return e.obs_norm if (self._norm and self._norm["norm_obs"]) else e.obs
 
     def stepAsync(self, actions):
@@ -241,10 +243,12 @@ class HipVecEnv(VecEnv):
         if self._actions is None:
             raise RuntimeError("stepWait() without stepAsync()")
         e = self.engine
-        e.step_begin(self._actions)
-        if self._has_norm():
+        if self._has_norm() and self.world > 1:
+            e.step_begin(self._actions)
             self._allreduce_moments()
-        e.step_finish()
+            e.step_finish()
+        else:
+            e.step(self._actions)   # single GPU: no exchange, one launch fewer (the normalise kernel folds the partial rows)
         self._actions = None
         obs = e.obs_norm if (self._norm and self._norm["norm_obs"]) else e.obs
         return VecEnvStepReturn(obs, e.reward.view(-1, 1), e.done.view(-1, 1), LazyInfos(self))

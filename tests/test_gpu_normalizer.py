@@ -288,3 +288,29 @@ def test_vecnormalize_template_flag_combinations(oracle, kind, training, norm_re
     if not (training and norm_reward):
         assert np.array_equal(st[2 * F + 1:], loaded[2 * F + 1:])                   # return statistics frozen
     assert eng.poll_error() == 0
+
+
+@pytest.mark.parametrize("kind,n", [("mountaincar", 1), ("mountaincar", 4097), ("cartpole", 70001), ("mountaincar", 1 << 20)])
+def test_unsplit_step_equals_begin_plus_finish_bit_for_bit(kind, n):
+    """gymhip_step / gymhip_reset launch two kernels (the normalise kernel folds the step kernel's partial rows in its
+    prologue); gymhip_*_begin + gymhip_*_finish launch three (the separate reduce feeds the all-reduce).  Same summation
+    function, same order: every output, the statistics and the moments buffer must agree bit for bit."""
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+    cart = kind == "cartpole"
+    w = L.WRAP_TIME_LIMIT | L.WRAP_MONITOR | (0 if cart else L.WRAP_CLIP_REWARD) | _norm_flags()
+    mk = lambda: Engine(EngineConfig(env_kind=L.ENV_CARTPOLE if cart else L.ENV_MOUNTAINCAR, n_envs=n, reset_mode=L.RESET_COUNTER_RNG, wrappers=w,
+                                     max_episode_steps=37, seed=3), 0)
+    a, b = mk(), mk()
+    a.reset()
+    b.reset_begin(); b.reset_finish()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for t in range(60):
+        act = torch.randint(0, 2 if cart else 3, (n,), dtype=torch.int32, device="cuda", generator=g)
+        a.step(act)
+        b.step_begin(act); b.step_finish()
+        if t % 7 == 0 or t == 59:
+            for k in ("obs", "obs_norm", "reward", "done", "returns", "counter", "norm_stats", "moments"):
+                assert torch.equal(getattr(a, k), getattr(b, k)), (t, k)
+    assert np.array_equal(a.episode_stats(), b.episode_stats()) and a.episode_stats()[0] > 0
+    assert a.poll_error() == 0 and b.poll_error() == 0

@@ -34,7 +34,7 @@ def test_noalloc_update_equals_update_on_two_calls_second_smaller(kind):
     a.reset(); b.reset()
     g = torch.Generator(device="cuda").manual_seed(11)
     prev_count = a.get_norm_stats()[2 * F]
-    # first call: 700,001 rows -> the full 1024-row partial grid; second: 3,001 rows -> 12 partial rows; third: one row
+    # first call: 700,001 rows -> the full partial grid (512 rows); second: 3,001 rows -> 6 partial rows; third: one row
     for k, rows in enumerate((700_001, 3_001, 1)):
         obs = (torch.randn((rows, F), device="cuda", generator=g) * 0.3 - 0.5).contiguous()
         rew = (torch.randn((rows,), device="cuda", generator=g) * 3).contiguous() if k != 1 else None
