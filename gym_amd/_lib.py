@@ -87,6 +87,8 @@ SIGNATURES = {
     "gymhip_upload_reset_tape": (C.c_int, [_vp, _vp, _i64]),
     "gymhip_seed_reset_tape": (C.c_int, [_vp, _u64, _i64]),
     "gymhip_unseeded_reset_tape": (C.c_int, [_vp, _i64]),
+    "gymhip_tape_cursor_max": (C.c_int, [_vp, _vp, _vp]),
+    "gymhip_extend_reset_tape": (C.c_int, [_vp, _i64]),
     "gymhip_generate_reset_tape": (C.c_int, [_vp, _i64, _vp]),
     "gymhip_download_reset_tape": (C.c_int, [_vp, _vp, _i64]),
     "gymhip_reset": (C.c_int, [_vp, _vp]),

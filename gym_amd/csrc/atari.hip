@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "gymhip.h"
@@ -272,43 +273,62 @@ __global__ __launch_bounds__(kBlock) void materialize_nhwc_kernel(const uint8_t*
     }
 }
 
-// ring -> NCHW f32 [N][k][P] = float(u8) / 255 (vec_atari.cpp:74-76), 4 pixels per thread.
-__global__ __launch_bounds__(kBlock) void materialize_nchw_f32_kernel(const uint8_t* ring, float* out, int64_t n, int P, int k, int head) {
-    const int P4 = P / 4;
-    const int64_t total = n * (int64_t)k * P4;
-    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < total; j += (int64_t)gridDim.x * kBlock) {
-        const int64_t ec = j / P4; const int q = (int)(j - ec * P4);
-        const int64_t e = ec / k; const int c = (int)(ec - e * k);
-        const uint32_t w = ((const uint32_t*)(ring + (e * k + ((head + 1 + c) % k)) * (int64_t)P))[q];
-        float4 v = make_float4((float)(w & 255u) / 255.f, (float)((w >> 8) & 255u) / 255.f, (float)((w >> 16) & 255u) / 255.f, (float)(w >> 24) / 255.f);
-        ((float4*)out)[j] = v;
-    }
-}
-
-// The same view in a 16-bit float type for half-precision policies: x / 255 computed in float32 exactly as above, then rounded
-// once, to nearest even, to IEEE half (BF16 = 0) or bfloat16 (BF16 = 1).  8 pixels (16 B out) per thread when P allows.
+// ring -> NCHW [N][k][P] = float(u8) / 255 (vec_atari.cpp:74-76).  A write-dominated stream (1 B in, 4 or 2 B out per pixel,
+// 231-462 MB per 4096-env call, written once and far larger than the Infinity Cache), so: non-temporal loads and stores, a
+// workgroup owns one contiguous piece of one (env, channel) plane — the ring-slot arithmetic is per workgroup and scalar, no
+// per-element integer division — and the launch has tens of thousands of workgroups (profiles/r01_stream_ceiling.txt: a
+// non-temporal write-only stream runs at 4.8 TB/s from 1024 workgroups, 6.8 TB/s from 65,536).
+// PX pixels per thread-item: 4 (f32: 4 B in, 16 B out) or 8 / 4 (16-bit: 8 B in, 16 B out / 4 B in, 8 B out).
+using u32x2v = uint32_t __attribute__((ext_vector_type(2)));
+using u32x4v = uint32_t __attribute__((ext_vector_type(4)));
+using f32x4v = float __attribute__((ext_vector_type(4)));
 template <int BF16> __device__ inline uint32_t to16(float v) {
-    if (BF16) { const uint32_t u = __float_as_uint(v); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; }   // finite, non-negative input
+    if (BF16) { const uint32_t u = __float_as_uint(v); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; }   // finite, non-negative input: round to nearest even
     return (uint32_t)__half_as_ushort(__float2half_rn(v));
 }
-template <int BF16, int VEC>
-__global__ __launch_bounds__(kBlock) void materialize_nchw_16_kernel(const uint8_t* ring, uint16_t* out, int64_t n, int P, int k, int head) {
-    const int PV = P / VEC;
-    const int64_t total = n * (int64_t)k * PV;
-    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < total; j += (int64_t)gridDim.x * kBlock) {
-        const int64_t ec = j / PV; const int q = (int)(j - ec * PV);
-        const int64_t e = ec / k; const int c = (int)(ec - e * k);
-        const uint32_t* src = (const uint32_t*)(ring + (e * k + ((head + 1 + c) % k)) * (int64_t)P) + q * (VEC / 4);
-        uint32_t o[VEC / 2];
+__device__ inline float px(uint32_t w, int b) { return (float)((w >> (8 * b)) & 255u) / 255.f; }
+template <int BF16> __device__ inline uint32_t pack16(uint32_t w, int b) { return to16<BF16>(px(w, b)) | (to16<BF16>(px(w, b + 1)) << 16); }
+
+// MODE 0: f32 out, 4 px per item.  MODE 1: 16-bit out, 8 px per item.  MODE 2: 16-bit out, 4 px per item (P % 8 != 0).
+#ifndef GYMHIP_MAT_BLOCK
+#define GYMHIP_MAT_BLOCK 256
+#endif
+#ifndef GYMHIP_MAT_UNR
+#define GYMHIP_MAT_UNR 4       // items whose loads are issued before the first of them is converted and stored
+#endif
+constexpr int kMatBlock = GYMHIP_MAT_BLOCK;
+template <int MODE, int BF16>
+__global__ __launch_bounds__(kMatBlock) void materialize_nchw_kernel(const uint8_t* __restrict__ ring, void* __restrict__ out, int64_t planes, int P, int k, int head, int split) {
+    constexpr int PX = MODE == 1 ? 8 : 4;
+    constexpr int UNR = GYMHIP_MAT_UNR;
+    using InV = typename std::conditional<MODE == 1, u32x2v, uint32_t>::type;
+    const int items = P / PX;                                        // per plane
+    const int per_piece = (items + split - 1) / split;
+    for (int64_t w = blockIdx.x; w < planes * split; w += gridDim.x) {
+        const int64_t plane = w / split; const int piece = (int)(w - plane * split);
+        const int64_t e = plane / k; const int c = (int)(plane - e * k);
+        const InV* src = (const InV*)(ring + (e * k + ((head + 1 + c) % k)) * (int64_t)P);     // channel c = the (c+1)-th oldest frame
+        const int lo = piece * per_piece, hi = min(items, lo + per_piece);
+        for (int q0 = lo + (int)threadIdx.x; q0 < hi; q0 += kMatBlock * UNR) {
+            InV v[UNR];
 #pragma unroll
-        for (int v = 0; v < VEC / 4; v++) {
-            const uint32_t w = src[v];
-            o[2 * v] = to16<BF16>((float)(w & 255u) / 255.f) | (to16<BF16>((float)((w >> 8) & 255u) / 255.f) << 16);
-            o[2 * v + 1] = to16<BF16>((float)((w >> 16) & 255u) / 255.f) | (to16<BF16>((float)(w >> 24) / 255.f) << 16);
+            for (int u = 0; u < UNR; u++) { const int q = q0 + u * kMatBlock; if (q < hi) v[u] = __builtin_nontemporal_load(src + q); }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int q = q0 + u * kMatBlock;
+                if (q >= hi) continue;
+                if constexpr (MODE == 0) {
+                    const f32x4v o = {px(v[u], 0), px(v[u], 1), px(v[u], 2), px(v[u], 3)};
+                    __builtin_nontemporal_store(o, (f32x4v*)out + plane * items + q);
+                } else if constexpr (MODE == 1) {
+                    const u32x4v o = {pack16<BF16>(v[u].x, 0), pack16<BF16>(v[u].x, 2), pack16<BF16>(v[u].y, 0), pack16<BF16>(v[u].y, 2)};
+                    __builtin_nontemporal_store(o, (u32x4v*)out + plane * items + q);
+                } else {
+                    const u32x2v o = {pack16<BF16>(v[u], 0), pack16<BF16>(v[u], 2)};
+                    __builtin_nontemporal_store(o, (u32x2v*)out + plane * items + q);
+                }
+            }
         }
-        uint32_t* dst = (uint32_t*)out + j * (VEC / 2);
-#pragma unroll
-        for (int v = 0; v < VEC / 2; v++) dst[v] = o[v];
     }
 }
 
@@ -522,12 +542,27 @@ int gymhip_atari_materialize_nhwc(gymhip_atari* h, uint8_t* out, void* stream) {
     return GYMHIP_OK;
 }
 
+// Launch shape of the NCHW materialisation: `split` workgroups per (env, channel) plane, at most kMatMaxGrid workgroups (a
+// grid-stride loop covers the rest).  GYMHIP_MAT_SPLIT / GYMHIP_MAT_GRID override for sweeps (tools/sweep_materialize.sh).
+constexpr int kMatMaxGrid = 1 << 20;
+static void materialize_shape(int64_t planes, int items, int* split, unsigned* grid) {
+    int sp = (int)((2 * (int64_t)items + 7 * kMatBlock / 2) / (7 * kMatBlock));   // default: ~3.5 items per thread (14 KB out per workgroup), best of tools/sweep_materialize.sh
+    if (const char* e = getenv("GYMHIP_MAT_SPLIT")) { const int v = atoi(e); if (v > 0) sp = v; }
+    sp = std::max(1, std::min(sp, items));
+    int64_t g = planes * sp;
+    int64_t cap = kMatMaxGrid;
+    if (const char* e = getenv("GYMHIP_MAT_GRID")) { const int v = atoi(e); if (v > 0) cap = v; }
+    *split = sp; *grid = (unsigned)std::min<int64_t>(g, cap);
+}
+
 int gymhip_atari_materialize_nchw_f32(gymhip_atari* h, float* out, void* stream) {
     if (int rc = check_atari(h)) return rc;
     if (!out) return fail(GYMHIP_EINVAL, "out is null");
-    const int P = h->cfg.dst_h * h->cfg.dst_w;
-    // grid 2048 grid-stride: a one-block-per-tile launch (112,896 blocks) measured 6 % slower
-    hipLaunchKernelGGL(materialize_nchw_f32_kernel, dim3(2048), dim3(kBlock), 0, (hipStream_t)stream, h->ring, out, h->cfg.n_envs, P, h->cfg.n_stack, h->head);
+    const int P = h->cfg.dst_h * h->cfg.dst_w;       // dst_w % 4 == 0 (gymhip_atari_create) => P % 4 == 0
+    const int64_t planes = h->cfg.n_envs * h->cfg.n_stack;
+    int split; unsigned grid;
+    materialize_shape(planes, P / 4, &split, &grid);
+    hipLaunchKernelGGL((materialize_nchw_kernel<0, 0>), dim3(grid), dim3(kMatBlock), 0, (hipStream_t)stream, h->ring, (void*)out, planes, P, h->cfg.n_stack, h->head, split);
     HIP_TRY(hipGetLastError());
     return GYMHIP_OK;
 }
@@ -538,14 +573,16 @@ int gymhip_atari_materialize_nchw_16(gymhip_atari* h, void* out, int dtype, void
     if (dtype != GYMHIP_OUT_F16 && dtype != GYMHIP_OUT_BF16) return fail(GYMHIP_EINVAL, "dtype must be GYMHIP_OUT_F16 or GYMHIP_OUT_BF16");
     const int P = h->cfg.dst_h * h->cfg.dst_w;
     hipStream_t s = (hipStream_t)stream;
-    uint16_t* o = (uint16_t*)out;
-    const int64_t n = h->cfg.n_envs; const int k = h->cfg.n_stack, head = h->head;
+    const int64_t planes = h->cfg.n_envs * h->cfg.n_stack; const int k = h->cfg.n_stack, head = h->head;
+    int split; unsigned grid;
     if (P % 8 == 0) {
-        if (dtype == GYMHIP_OUT_BF16) hipLaunchKernelGGL((materialize_nchw_16_kernel<1, 8>), dim3(2048), dim3(kBlock), 0, s, h->ring, o, n, P, k, head);
-        else hipLaunchKernelGGL((materialize_nchw_16_kernel<0, 8>), dim3(2048), dim3(kBlock), 0, s, h->ring, o, n, P, k, head);
+        materialize_shape(planes, P / 8, &split, &grid);
+        if (dtype == GYMHIP_OUT_BF16) hipLaunchKernelGGL((materialize_nchw_kernel<1, 1>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, head, split);
+        else hipLaunchKernelGGL((materialize_nchw_kernel<1, 0>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, head, split);
     } else {
-        if (dtype == GYMHIP_OUT_BF16) hipLaunchKernelGGL((materialize_nchw_16_kernel<1, 4>), dim3(2048), dim3(kBlock), 0, s, h->ring, o, n, P, k, head);
-        else hipLaunchKernelGGL((materialize_nchw_16_kernel<0, 4>), dim3(2048), dim3(kBlock), 0, s, h->ring, o, n, P, k, head);
+        materialize_shape(planes, P / 4, &split, &grid);
+        if (dtype == GYMHIP_OUT_BF16) hipLaunchKernelGGL((materialize_nchw_kernel<2, 1>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, head, split);
+        else hipLaunchKernelGGL((materialize_nchw_kernel<2, 0>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, head, split);
     }
     HIP_TRY(hipGetLastError());
     return GYMHIP_OK;

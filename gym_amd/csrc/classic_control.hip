@@ -928,6 +928,16 @@ __global__ __launch_bounds__(kBlock) void rewind_tape_cursor_kernel(uint32_t* co
         counter[i] &= ~(W::kCursorMask << W::S);
 }
 
+// Largest reset-tape cursor over all envs (rows consumed by the env that consumed most) -> *out (zeroed by the caller).
+__global__ __launch_bounds__(kBlock) void tape_cursor_max_kernel(const uint32_t* counter, int64_t n, int32_t* out) {
+    using W = CounterWord<KIND_CARTPOLE>;
+    int m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) m = max(m, (int)W::cursor(counter[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+
 __global__ __launch_bounds__(kBlock) void fill_tape_kernel(float4* tape, int64_t n, int64_t episodes, uint64_t seed, int64_t env_offset) {
     const int64_t total = n * episodes;
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < total; j += (int64_t)gridDim.x * kBlock) {
@@ -950,7 +960,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
     size_t state, obs, obs_norm, reward, done, counter, returns;
-    size_t stats /*3 slots*/, moments, partials, ep_partials, ep_totals, ep_totals_global, error_flag, total;
+    size_t stats /*3 slots*/, moments, partials, ep_partials, ep_totals, ep_totals_global, error_flag, cursor_max, total;
 };
 
 int obs_dim_of(int kind) { return kind == KIND_CARTPOLE ? 4 : 2; }
@@ -1002,6 +1012,7 @@ Layout make_layout(const gymhip_config& c) {
     L.ep_totals = take(4 * 8);
     L.ep_totals_global = take(4 * 8);
     L.error_flag = take(4);
+    L.cursor_max = take(4);
     L.total = off;
     return L;
 }
@@ -1034,6 +1045,9 @@ struct gymhip_engine {
     int stats_slot;          // ping-pong slot holding the current running statistics
     float* tape;
     int64_t tape_episodes;
+    int tape_source;         // 0 = none / uploaded / device-generated, 1 = drawn on the host with std::mt19937 (can be extended)
+    bool tape_seeded;        // host-drawn tape: were the envs seeded (seed + index) or default-constructed
+    uint64_t tape_seed;
     bool did_reset;
     bool pending_finish;     // a *_begin with the normaliser on awaits its *_finish
     bool pending_is_reset;
@@ -1204,7 +1218,7 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
     h->grid = grid_for(cfg->n_envs);
     h->norm = cfg->wrappers & (GYMHIP_WRAP_NORM_OBS | GYMHIP_WRAP_NORM_REWARD);
     h->stats_slot = 0;
-    h->tape = nullptr; h->tape_episodes = 0;
+    h->tape = nullptr; h->tape_episodes = 0; h->tape_source = 0; h->tape_seeded = false; h->tape_seed = 0;
     h->did_reset = false; h->pending_finish = false; h->pending_is_reset = false;
     h->step_counter = 0;
     // Non-temporal streaming pays only once the per-step footprint (workspace + an int32 action row) no longer fits the
@@ -1293,15 +1307,24 @@ int gymhip_upload_reset_tape(gymhip_engine* h, const float* host_tape, int64_t e
     if (int rc = ensure_tape(h, episodes)) return rc;
     HIP_TRY(hipDeviceSynchronize());   // no stream argument here: nothing of this engine may still be reading the old rows
     HIP_TRY(hipMemcpy(h->tape, host_tape, (size_t)episodes * h->cfg.n_envs * 16, hipMemcpyHostToDevice));
+    h->tape_source = 0;
     if (int rc = rewind_tape_cursors(h, nullptr)) return rc;
     HIP_TRY(hipDeviceSynchronize());
     return GYMHIP_OK;
 }
 
-static int draw_reset_tape(gymhip_engine* h, bool seeded, uint64_t seed, int64_t episodes);
-int gymhip_seed_reset_tape(gymhip_engine* h, uint64_t seed, int64_t episodes) { return draw_reset_tape(h, true, seed, episodes); }
-int gymhip_unseeded_reset_tape(gymhip_engine* h, int64_t episodes) { return draw_reset_tape(h, false, 0, episodes); }
-static int draw_reset_tape(gymhip_engine* h, bool seeded, uint64_t seed, int64_t episodes) {
+static int draw_reset_tape(gymhip_engine* h, bool seeded, uint64_t seed, int64_t episodes, bool rewind);
+int gymhip_seed_reset_tape(gymhip_engine* h, uint64_t seed, int64_t episodes) { return draw_reset_tape(h, true, seed, episodes, true); }
+int gymhip_unseeded_reset_tape(gymhip_engine* h, int64_t episodes) { return draw_reset_tape(h, false, 0, episodes, true); }
+// More rows of the SAME streams: the tape is redrawn from the remembered seeds with `episodes` rows per env (a prefix of an
+// env's stream never changes) and the cursors stay where they are, so a running engine simply finds more rows.
+int gymhip_extend_reset_tape(gymhip_engine* h, int64_t episodes) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->tape || h->tape_source != 1) return fail(GYMHIP_ESTATE, "only a tape drawn by gymhip_seed_reset_tape / gymhip_unseeded_reset_tape can be extended");
+    if (episodes <= h->tape_episodes) return fail(GYMHIP_EINVAL, "the tape already holds %lld rows per env", (long long)h->tape_episodes);
+    return draw_reset_tape(h, h->tape_seeded, h->tape_seed, episodes, false);
+}
+static int draw_reset_tape(gymhip_engine* h, bool seeded, uint64_t seed, int64_t episodes, bool rewind) {
     if (int rc = check_handle(h)) return rc;
     if (int rc = ensure_tape(h, episodes)) return rc;
     // The reference's own generator, called the way it calls it: env i owns std::mt19937 seeded `seed + i`
@@ -1330,10 +1353,25 @@ static int draw_reset_tape(gymhip_engine* h, bool seeded, uint64_t seed, int64_t
     }
     for (auto& th : pool) th.join();
     if (seeded) h->cfg.seed = seed;
+    h->tape_source = 1; h->tape_seeded = seeded; h->tape_seed = seed;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h->tape, tape.data(), tape.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (int rc = rewind_tape_cursors(h, nullptr)) return rc;
+    if (rewind) { if (int rc = rewind_tape_cursors(h, nullptr)) return rc; }
     HIP_TRY(hipDeviceSynchronize());
+    return GYMHIP_OK;
+}
+
+int gymhip_tape_cursor_max(gymhip_engine* h, int32_t* host_out, void* stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (!host_out) return fail(GYMHIP_EINVAL, "host_out is null");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t* slot = h->at<int32_t>(h->L.cursor_max);
+    HIP_TRY(hipMemsetAsync(slot, 0, 4, s));
+    if (h->cfg.env_kind == KIND_CARTPOLE && h->cfg.reset_mode == GYMHIP_RESET_TAPE)
+        hipLaunchKernelGGL(tape_cursor_max_kernel, dim3(h->grid), dim3(kBlock), 0, s, h->at<uint32_t>(h->L.counter), h->cfg.n_envs, slot);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host_out, slot, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return GYMHIP_OK;
 }
 
@@ -1342,6 +1380,7 @@ int gymhip_generate_reset_tape(gymhip_engine* h, int64_t episodes, void* stream)
     if (int rc = ensure_tape(h, episodes)) return rc;
     hipLaunchKernelGGL(fill_tape_kernel, dim3(kMaxGrid), dim3(kBlock), 0, (hipStream_t)stream, (float4*)h->tape, h->cfg.n_envs, episodes, h->cfg.seed, h->cfg.env_offset);
     HIP_TRY(hipGetLastError());
+    h->tape_source = 0;
     return rewind_tape_cursors(h, (hipStream_t)stream);
 }
 

@@ -125,6 +125,16 @@ class Engine:
     def seed_reset_tape_unseeded(self, episodes: int):
         L.check(self.lib.gymhip_unseeded_reset_tape(self.h, episodes), "gymhip_unseeded_reset_tape")
 
+    def tape_cursor_max(self) -> int:
+        """Rows of the reset tape consumed so far by the env that consumed most (synchronises the stream)."""
+        v = C.c_int32(0)
+        L.check(self.lib.gymhip_tape_cursor_max(self.h, C.byref(v), self._stream()), "gymhip_tape_cursor_max")
+        return v.value
+
+    def extend_reset_tape(self, episodes: int):
+        """More rows of the same host-drawn std::mt19937 streams; cursors are kept."""
+        L.check(self.lib.gymhip_extend_reset_tape(self.h, episodes), "gymhip_extend_reset_tape")
+
     def generate_reset_tape(self, episodes: int):
         L.check(self.lib.gymhip_generate_reset_tape(self.h, episodes, self._stream()), "gymhip_generate_reset_tape")
 

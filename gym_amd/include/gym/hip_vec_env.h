@@ -3,16 +3,27 @@
 // (wrappers/vec_env/sync_env.h, vec_normalize.h) on one MI355X.  Header-only; all compute is behind the C ABI in
 // include/gymhip.h (libgymhip.so).  libtorch is used only to hand results back as torch::Tensor views of device memory.
 //
-// Inside the reference tree:   #define GYMHIP_USE_REFERENCE_HEADERS  +  #include "wrappers/vec_env/base.h"  first.
-// Elsewhere the stand-alone mirror in gym/vec_env.h supplies gym::VecEnv<false>.
+// Inside the reference tree:   #define GYMHIP_USE_REFERENCE_HEADERS, then #include "wrappers/vec_env/base.h" (VecEnv<false>,
+// spaces, AnyMap) and "wrappers/monitor.h" (gym::Result) BEFORE this header; oracle/ref_driver/ref_dropin_tu.cpp is that
+// configuration, compiled against the reference's headers where they lie by `make -C oracle _ref`.
+// Elsewhere the stand-alone mirror in gym/vec_env.h supplies the same names.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <functional>
+#include <limits>
+#include <stdexcept>
 #include <string>
 
+#ifdef GYMHIP_USE_REFERENCE_HEADERS
+#include "spaces/box.h"        // the reference's own Box<T> / Discrete (its include root must be on the include path)
+#include "spaces/discrete.h"
+#else
 #include "gym/vec_env.h"
+#endif
 #include "gymhip.h"
 
 namespace gym {
@@ -26,7 +37,8 @@ struct HipVecEnvOptions {
     bool monitor = true;                      // Monitor
     bool lockstep = true;                     // reference-exact arithmetic (double state); false = float-state throughput mode
     bool host_drawn_resets = true;            // std::mt19937 reset tape (reference-exact); false = stateless counter RNG
-    int64_t tape_episodes = 2048;             // reset-tape rows per env
+    int64_t tape_episodes = 0;                // reset-tape rows per env to start with; 0 = at most 256 MiB of rows, 8..2048 per env.
+                                              // The tape is extended (same std::mt19937 streams, twice the rows) before any env runs out.
     bool norm_obs = false, norm_reward = false, training = true;   // VecNormalize<false, training, normReward, normObs>
     float clip_obs = 10.f, clip_rew = 10.f, gamma = 0.99f, epsilon = 1e-8f;   // vec_normalize.h:24-27
     int device = 0;
@@ -50,8 +62,8 @@ public:
     std::vector<size_t> seed(size_t _seed) noexcept override {   // sync_env.h:74-83
         seeded = true; seed_value = _seed;
         if (h) {   // mid-run re-seed: every env's generator restarts, exactly as Env::seed does (env.h:60-63)
-            const bool tape = opt.host_drawn_resets && opt.env_kind == GYMHIP_ENV_CARTPOLE;
-            ok(tape ? gymhip_seed_reset_tape(h, _seed, opt.tape_episodes) : gymhip_seed(h, _seed), "seed");
+            if (usesTape()) { if (ok(gymhip_seed_reset_tape(h, _seed, tape_rows), "gymhip_seed_reset_tape")) tape_budget = tapeStepsFor(tape_rows); }
+            else ok(gymhip_seed(h, _seed), "gymhip_seed");
         }
         std::vector<size_t> s(numEnvs);
         for (int i = 0; i < numEnvs; i++) s[i] = _seed + (size_t)opt.env_offset + (size_t)i;
@@ -59,7 +71,7 @@ public:
     }
 
     torch::Tensor reset() noexcept override {   // sync_env.h:66-72 / vec_normalize.h:145-157
-        if (!ensure()) return {};
+        if (!ensure() || !tapeSpend(minEpisodeSteps())) return {};
         if (hasNorm() && opt.allreduce) {   // sharded: batch moments all-reduced between the two halves
             if (!ok(gymhip_reset_begin(h, opt.stream), "gymhip_reset_begin")) return {};
             opt.allreduce(buf.moments, (size_t)buf.moments_len, opt.stream);
@@ -74,7 +86,7 @@ public:
     }
 
     StepT stepWait() noexcept override {   // sync_env.h:114-123 / vec_normalize.h:159-177
-        if (!h || !pending.defined()) { std::fprintf(stderr, "HipVecEnv::stepWait before reset()/stepAsync()\n"); return {}; }
+        if (!ready || !pending.defined()) { std::fprintf(stderr, "HipVecEnv::stepWait before reset()/stepAsync()\n"); return {}; }
         torch::Tensor a = pending;
         int dt;
         if (a.is_cuda() && a.is_contiguous() && a.scalar_type() == torch::kInt32) dt = GYMHIP_ACT_I32;
@@ -82,6 +94,7 @@ public:
         else if (a.is_cuda() && a.is_contiguous() && a.scalar_type() == torch::kUInt8) dt = GYMHIP_ACT_U8;
         else { a = a.to(torch::Device(torch::kCUDA, opt.device), torch::kInt32).contiguous(); dt = GYMHIP_ACT_I32; }
         if (a.numel() != numEnvs) { std::fprintf(stderr, "HipVecEnv: expected %d actions, got %lld\n", numEnvs, (long long)a.numel()); return {}; }
+        if (!tapeSpend(1)) return {};
         if (hasNorm() && opt.allreduce) {
             if (!ok(gymhip_step_begin(h, a.data_ptr(), dt, opt.stream), "gymhip_step_begin")) return {};
             opt.allreduce(buf.moments, (size_t)buf.moments_len, opt.stream);
@@ -93,8 +106,20 @@ public:
 
     // info maps for the envs that just finished (monitor.h:86-97, time_limit.h:32), built on demand: N unordered_maps per
     // step are the reference's host bottleneck.  Entry i is empty unless done[i] != 0.  Synchronises the stream.
+    AnyMap infoOf(int index) {   // one env's map (synchronises the stream)
+        AnyMap m;
+        if (!ready || done[index].item<float>() == 0.f) return m;
+        auto o = torch::TensorOptions().device(torch::kCUDA, opt.device);
+        auto len = torch::empty({numEnvs}, o.dtype(torch::kInt32)), tr = torch::empty({numEnvs}, o.dtype(torch::kUInt8)), ret = torch::empty({numEnvs}, o.dtype(torch::kFloat32));
+        if (!ok(gymhip_decode_counters(h, nullptr, len.data_ptr<int32_t>(), tr.data_ptr<uint8_t>(), ret.data_ptr<float>(), nullptr, opt.stream), "gymhip_decode_counters")) return m;
+        float t = std::chrono::duration<float>(std::chrono::high_resolution_clock::now() - t_start).count();
+        if (opt.max_episode_steps > 0) m["TimeLimit.truncated"] = bool(tr[index].item<uint8_t>());
+        if (opt.monitor) m["episode"] = Result{ret[index].item<float>(), float(len[index].item<int32_t>()), t};
+        return m;
+    }
     std::vector<AnyMap> infos() {
         std::vector<AnyMap> out(numEnvs);
+        if (!ready) return out;
         auto o = torch::TensorOptions().device(torch::kCUDA, opt.device);
         auto len = torch::empty({numEnvs}, o.dtype(torch::kInt32)), tr = torch::empty({numEnvs}, o.dtype(torch::kUInt8)), ret = torch::empty({numEnvs}, o.dtype(torch::kFloat32));
         if (!ok(gymhip_decode_counters(h, nullptr, len.data_ptr<int32_t>(), tr.data_ptr<uint8_t>(), ret.data_ptr<float>(), nullptr, opt.stream), "gymhip_decode_counters")) return out;
@@ -158,7 +183,8 @@ public:
 
     // sync_env.h:128-139 (+ vec_normalize.h:179-189 with the normaliser fused in): one env is reset; returns its row
     torch::Tensor reset(int index) override {
-        if (!h) throw std::runtime_error("HipVecEnv::reset(int index) before reset()");
+        if (!ready) throw std::runtime_error("HipVecEnv::reset(int index) before reset()");
+        if (!tapeSpend(minEpisodeSteps())) throw std::runtime_error("HipVecEnv: reset tape exhausted");
         if (gymhip_reset_index(h, index, opt.stream) != GYMHIP_OK) throw std::runtime_error(gymhip_last_error());
         return (opt.norm_obs ? obs_norm : obs)[index];
     }
@@ -171,7 +197,13 @@ public:
         ok(gymhip_update_norm_stats(h, s.defined() ? s.data_ptr<float>() : nullptr, s.defined() ? s.size(0) : 0,
                                     r.defined() ? r.data_ptr<float>() : nullptr, r.defined() ? r.size(0) : 0, opt.stream), "gymhip_update_norm_stats");
     }
-    StepT step(int, torch::Tensor const&) noexcept override { return {}; }   // the reference's own stub returns buffered values (sync_env.h:141-157)
+    // The reference's per-index step is a stub that does not step: it returns the BUFFERED reward / done of env `index` as
+    // [1] tensors and its buffered info map (sync_env.h:141-157; the observation line is commented out there — the buffered
+    // row is returned here, as that code intended).
+    StepT step(int index, torch::Tensor const&) noexcept override {
+        if (!ready || index < 0 || index >= numEnvs) { std::fprintf(stderr, "HipVecEnv::step(index): no buffered step for env %d\n", index); return {}; }
+        return {(opt.norm_obs ? obs_norm : obs)[index], reward[index].unsqueeze(-1), done[index].unsqueeze(-1), {infoOf(index)}};
+    }
     void render() const override {}
 
 private:
@@ -194,12 +226,12 @@ private:
         return torch::from_blob((void*)p, shape, torch::TensorOptions().dtype(dt).device(torch::kCUDA, opt.device));
     }
     bool ensure() noexcept {
-        if (h) return true;
+        if (ready) return true;
         gymhip_config c{};
         c.struct_size = sizeof c;
         c.env_kind = opt.env_kind;
         c.precision = opt.lockstep ? GYMHIP_PRECISION_LOCKSTEP_F64 : GYMHIP_PRECISION_F32;
-        const bool tape = opt.host_drawn_resets && opt.env_kind == GYMHIP_ENV_CARTPOLE;
+        const bool tape = usesTape();
         c.reset_mode = tape ? GYMHIP_RESET_TAPE : GYMHIP_RESET_COUNTER_RNG;
         auto flag = [](bool on, uint32_t bit) { return on ? bit : 0u; };
         c.wrappers = flag(opt.max_episode_steps > 0, GYMHIP_WRAP_TIME_LIMIT) | flag(opt.clip_reward, GYMHIP_WRAP_CLIP_REWARD) |
@@ -209,19 +241,52 @@ private:
         c.n_envs = opt.n_envs; c.env_offset = opt.env_offset; c.seed = seeded ? seed_value : 0;
         c.clip_obs = opt.clip_obs; c.clip_reward = opt.clip_rew; c.gamma = opt.gamma; c.epsilon = opt.epsilon;
         if (!ok(gymhip_create(&c, opt.device, nullptr, 0, &h), "gymhip_create")) { h = nullptr; return false; }
-        if (tape && !ok(seeded ? gymhip_seed_reset_tape(h, seed_value, opt.tape_episodes) : gymhip_unseeded_reset_tape(h, opt.tape_episodes), "reset tape")) return false;
-        if (!ok(gymhip_get_buffers(h, &buf), "gymhip_get_buffers")) return false;
+        // any failure after create leaves NO half-built engine behind: the handle is destroyed and the next call starts over
+        auto giveUp = [this]() { gymhip_destroy(h); h = nullptr; return false; };
+        if (tape) {
+            if (tape_rows <= 0) tape_rows = opt.tape_episodes > 0 ? opt.tape_episodes : std::min<int64_t>(2048, std::max<int64_t>(8, ((int64_t)256 << 20) / (16 * std::max<int64_t>(1, opt.n_envs))));
+            if (!ok(seeded ? gymhip_seed_reset_tape(h, seed_value, tape_rows) : gymhip_unseeded_reset_tape(h, tape_rows), "reset tape")) return giveUp();
+            tape_budget = tapeStepsFor(tape_rows);
+        }
+        if (!ok(gymhip_get_buffers(h, &buf), "gymhip_get_buffers")) return giveUp();
         const int64_t n = opt.n_envs, F = buf.obs_dim;
         obs = view(buf.obs, {n, F}, c10::kFloat);
         obs_norm = view(buf.obs_norm, {n, F}, c10::kFloat);
         reward = view(buf.reward, {n}, c10::kFloat);
         done = view(buf.done, {n}, c10::kFloat);
         norm_stats = view(buf.norm_stats, {2 * F + 4}, c10::kFloat);
+        if (!obs.defined() || !reward.defined() || !done.defined() || (opt.norm_obs && !obs_norm.defined())) return giveUp();
+        ready = true;
+        return true;
+    }
+
+    // Reset-tape guard.  An env consumes one tape row per finished episode and per reset; no CartPole episode is shorter than
+    // min(8, TimeLimit) steps (cartpole.cpp:19-68, enumerated), so with r rows left for the env that consumed most, 8 (r - 1)
+    // further steps cannot exhaust the tape.  When that budget is spent: one 4-byte read-back of the largest cursor, and with
+    // under a quarter of the rows left the tape is redrawn from the same std::mt19937 streams with twice the rows.
+    bool usesTape() const { return opt.host_drawn_resets && opt.env_kind == GYMHIP_ENV_CARTPOLE; }
+    int64_t minEpisodeSteps() const { return opt.max_episode_steps > 0 ? std::max<int64_t>(1, std::min<int64_t>(8, opt.max_episode_steps)) : 8; }
+    int64_t tapeStepsFor(int64_t rows_left) const { return std::max<int64_t>(0, minEpisodeSteps() * (rows_left - 1)); }
+    bool tapeSpend(int64_t steps) noexcept {
+        if (!usesTape() || !h) return true;
+        tape_budget -= steps;
+        if (tape_budget > 0) return true;
+        int32_t err = 0, used = 0;
+        if (!ok(gymhip_poll_error(h, &err, opt.stream), "gymhip_poll_error") || !ok(gymhip_tape_cursor_max(h, &used, opt.stream), "gymhip_tape_cursor_max")) return false;
+        if (err & 1) { std::fprintf(stderr, "HipVecEnv: reset tape exhausted — an env replayed old reset states\n"); return false; }
+        if (tape_rows - used < std::max<int64_t>(8, tape_rows / 4)) {
+            const int64_t want = std::max<int64_t>(2 * tape_rows, (int64_t)used + 16);
+            if (!ok(gymhip_extend_reset_tape(h, want), "gymhip_extend_reset_tape")) return false;
+            tape_rows = want;
+        }
+        tape_budget = tapeStepsFor(tape_rows - used);
         return true;
     }
 
     HipVecEnvOptions opt;
     gymhip_engine* h = nullptr;
+    bool ready = false;            // set only once the engine, its tape and the tensor views all exist
+    int64_t tape_rows = 0, tape_budget = 0;
     gymhip_buffers buf{};
     torch::Tensor obs, obs_norm, reward, done, norm_stats, pending;
     bool seeded = false;

@@ -1,6 +1,7 @@
-"""Host-side mirror of the reference's spaces (spaces/space.h:20-104, box.h:15-54, discrete.h:14-31, util.h:18-26,
-common/utils.h:82-122).  Only what the hot path's VecEnv interface exposes: Box / Discrete with size(), type(),
-getRange(), sample(), clone(), as_()."""
+"""Host-side mirror of the reference's spaces (spaces/space.h:20-104, box.h:15-54, box.tpp:7-18, discrete.h:14-31,
+discrete.cpp:15-21, util.h:18-97, common/utils.h:82-122).  Only what the hot path's VecEnv interface exposes: Box / Discrete
+with size(), type(), getRange(), sample(), clone(), as_().  Checked against what the reference's own spaces code reports
+(tests/golden/ref_spaces.json, produced by oracle/_ref/ref_spaces_driver; tests/test_ref_pin.py)."""
 from __future__ import annotations
 
 import copy
@@ -45,9 +46,24 @@ class Space:
         return copy.deepcopy(self)
 
 
+# util.h:58-102 make_shape<T>: the dtype a space reports.  uint8_t maps to c10::kChar (int8) in the reference — kept.
+_REPORTED_DTYPE = {np.dtype(np.uint8): np.dtype(np.int8)}
+
+
+def make_shape_dtype(dtype):
+    d = np.dtype(dtype)
+    return _REPORTED_DTYPE.get(d, d)
+
+
 class Box(Space):
     def __init__(self, low=None, high=None, shape=(1,), dtype=np.float32):
-        super().__init__(shape, dtype)
+        super().__init__(shape, make_shape_dtype(dtype))
+        self._value_dtype = np.dtype(dtype)
+        vectorised = low is not None and np.ndim(low) > 0
+        if vectorised and len(self._shape) != 1:
+            # box.tpp:7-18: a vector of ranges needs a shape with exactly one dim
+            raise RuntimeError("a zero dim shape is not allowed" if len(self._shape) == 0 else
+                               "initializing a Box with a vectorized range requires a shape with only one dim")
         if low is None and high is None:
             # Box(Shape) ctor: one range {numeric_limits<T>::min(), max()} (box.h:31-34)
             info = np.finfo(dtype) if np.issubdtype(np.dtype(dtype), np.floating) else np.iinfo(dtype)
@@ -65,7 +81,7 @@ class Box(Space):
     def sample(self):
         lo = np.array([r.low for r in self._ranges], np.float64)
         hi = np.array([r.high for r in self._ranges], np.float64)
-        return self._rng.uniform(np.maximum(lo, -1e30), np.minimum(hi, 1e30)).astype(self._dtype)
+        return self._rng.uniform(np.maximum(lo, -1e30), np.minimum(hi, 1e30)).astype(self._value_dtype)
 
     def __repr__(self):
         return f"Box(shape={self._shape}, dtype={self._dtype}, ranges={self._ranges})"
@@ -74,8 +90,8 @@ class Box(Space):
 class Discrete(Space):
     def __init__(self, n: int):
         if n <= 0:
-            raise ValueError("Discrete: n must be positive")   # discrete.cpp:19-20
-        super().__init__((1,), np.int32)
+            raise ValueError("discrete space only accepts dim > 0")   # discrete.cpp:19-20 (std::invalid_argument)
+        super().__init__((int(n),), np.int32)                          # discrete.cpp:16: the shape is {n}
         self.n = int(n)
 
     def sample(self):

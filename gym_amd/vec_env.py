@@ -39,11 +39,18 @@ class VecEnvStepReturn(NamedTuple):
 class LazyInfos:
     """vector<AnyMap> info (base.h:24) built on demand: N unordered_maps per step are the reference's host bottleneck at
     large N, so maps are materialised only when indexed, and only finished envs have entries:
-    info[i]["episode"] = {"r", "l", "t"} (monitor.h:86-97), info[i]["TimeLimit.truncated"] (time_limit.h:32)."""
+    info[i]["episode"] = {"r", "l", "t"} (monitor.h:86-97), info[i]["TimeLimit.truncated"] (time_limit.h:32).
+
+    The reference hands out concrete per-step maps (sync_env.h:101,111); this object reads the engine's buffers on first
+    use, so it is only valid until the engine steps again.  It is stamped with the engine's step count at creation and
+    RAISES if indexed after a later step (a rollout buffer that keeps `step().info` must read it, or call `.materialize()`,
+    before the next step)."""
 
     def __init__(self, venv: "HipVecEnv"):
         self._venv = venv
         self._host = None
+        self._stamp = venv._steps_taken
+        self._t = time.perf_counter() - venv._t_start
 
     def __len__(self):
         return self._venv.numEnvs
@@ -51,11 +58,18 @@ class LazyInfos:
     def _fetch(self):
         if self._host is None:
             v = self._venv
+            if v._steps_taken != self._stamp:
+                raise RuntimeError("this step's info was not read before the next step(): the engine's episode records have been "
+                                   "overwritten (read info, or call info.materialize(), before stepping again)")
             ln, tr, ret = v.engine.episode_info()
             done = v.engine.done
-            self._host = dict(done=done.cpu().numpy() != 0, length=ln.cpu().numpy(), truncated=tr.cpu().numpy() != 0, ret=ret.cpu().numpy(),
-                              t=time.perf_counter() - v._t_start)
+            self._host = dict(done=done.cpu().numpy() != 0, length=ln.cpu().numpy(), truncated=tr.cpu().numpy() != 0, ret=ret.cpu().numpy(), t=self._t)
         return self._host
+
+    def materialize(self):
+        """Copy this step's records to the host now; the object then stays valid across later steps."""
+        self._fetch()
+        return self
 
     def done_indices(self):
         return np.nonzero(self._fetch()["done"])[0]
@@ -143,7 +157,7 @@ class HipVecEnv(VecEnv):
     """
 
     def __init__(self, env_id: str, n_envs: int, max_episode_steps: int | None = None, clip_reward: bool = False, monitor: bool = True,
-                 lockstep: bool = True, reset_mode: str = "tape", tape_episodes: int = 2048, device: int | None = None,
+                 lockstep: bool = True, reset_mode: str = "tape", tape_episodes: int | None = None, device: int | None = None,
                  rank: int | None = None, world: int | None = None, process_group=None, auto_reset: bool = True):
         if env_id not in _ENV_IDS:
             raise ValueError(f"unknown env id {env_id!r}; the engine implements {sorted(_ENV_IDS)}")
@@ -162,7 +176,13 @@ class HipVecEnv(VecEnv):
         self._max_steps = int(max_episode_steps or 0)
         self._lockstep = lockstep
         self._reset_mode = L.RESET_TAPE if (reset_mode == "tape" and self.kind == L.ENV_CARTPOLE) else L.RESET_COUNTER_RNG
-        self._tape_episodes = tape_episodes
+        # Host-drawn reset tape: start with at most 256 MiB of rows (16 B each), at least 8 and at most 2048 per env; the tape
+        # guard below extends it (same streams, twice the rows) before any env can run out.
+        if tape_episodes is None:
+            tape_episodes = int(min(2048, max(8, (256 << 20) // (16 * max(1, hi - lo)))))
+        self._tape_episodes = int(tape_episodes)
+        self._steps_taken = 0
+        self._tape_budget = 0      # VecEnv steps that may still be taken before the tape cursors must be looked at again
         self._device = int(os.environ.get("LOCAL_RANK", 0)) if device is None else device
         self._norm = None          # set by VecNormalize before the engine exists
         self._seed = None          # unseeded envs keep default-constructed mt19937 (seed 5489) — identical streams
@@ -194,6 +214,35 @@ class HipVecEnv(VecEnv):
                 self.engine.seed_reset_tape_unseeded(self._tape_episodes)
             else:
                 self.engine.seed_reset_tape(self._seed, self._tape_episodes)
+            self._tape_budget = self._tape_steps_for(self._tape_episodes)
+
+    # -- reset-tape guard ------------------------------------------------------------------------------------------
+    # An env consumes one tape row per finished episode (and per reset).  No CartPole episode is shorter than 8 steps
+    # (enumerated over the corners of the reset box x every action sequence; cartpole.cpp:19-68) or than TimeLimit's bound,
+    # so with r rows left for the env that has consumed most, 8 r - 8 further steps cannot exhaust the tape.  When that budget
+    # is spent the cursors are looked at again (one 4-byte read-back) and, with less than a quarter of the rows left, the
+    # tape is redrawn from the same std::mt19937 streams with twice the rows.  The kernel's wrap-around (error bit 0) is thus
+    # never reached; it is still checked and raised.
+    def _min_episode_steps(self):
+        return max(1, min(8, self._max_steps) if (self._wrappers & L.WRAP_TIME_LIMIT) else 8)
+
+    def _tape_steps_for(self, rows_left):
+        return max(0, self._min_episode_steps() * (rows_left - 1))
+
+    def _tape_spend(self, steps):
+        if self._reset_mode != L.RESET_TAPE or self.engine is None:
+            return
+        self._tape_budget -= steps
+        if self._tape_budget > 0:
+            return
+        e = self.engine
+        if e.poll_error() & 1:
+            raise RuntimeError("reset tape exhausted: an env replayed old reset states (gymhip error bit 0)")
+        used = e.tape_cursor_max()
+        if self._tape_episodes - used < max(8, self._tape_episodes // 4):
+            self._tape_episodes = max(2 * self._tape_episodes, used + 16)
+            e.extend_reset_tape(self._tape_episodes)
+        self._tape_budget = self._tape_steps_for(self._tape_episodes - used)
 
     def _has_norm(self):
         return self._norm is not None and (self._norm["norm_obs"] or self._norm["norm_reward"])
@@ -209,6 +258,7 @@ class HipVecEnv(VecEnv):
         if self.engine is not None:   # mid-run re-seed: every env's generator restarts (env.h:60-63); the tape is redrawn, cursors rewound
             if self._reset_mode == L.RESET_TAPE:
                 self.engine.seed_reset_tape(self._seed, self._tape_episodes)
+                self._tape_budget = self._tape_steps_for(self._tape_episodes)
             else:
                 self.engine.seed(self._seed)
         return [self._seed + self.env_offset + i for i in range(self.numEnvs)] if self.numEnvs <= 1 << 20 else range(
@@ -221,11 +271,13 @@ class HipVecEnv(VecEnv):
                 raise RuntimeError("reset(index) before reset()")
             if not 0 <= int(index) < self.numEnvs:
                 raise IndexError(f"env index {index} out of range [0, {self.numEnvs})")
+            self._tape_spend(self._min_episode_steps())   # a reset consumes a tape row, like one shortest-possible episode
             self.engine.reset_index(int(index))
             e = self.engine
             return (e.obs_norm if (self._norm and self._norm["norm_obs"]) else e.obs)[int(index)]
         self._ensure_engine()
         e = self.engine
+        self._tape_spend(self._min_episode_steps())
         if self._has_norm() and self.world > 1:   # sharded: the batch moments are all-reduced between the two halves of the call
             e.reset_begin()
             self._allreduce_moments()
@@ -243,6 +295,8 @@ class HipVecEnv(VecEnv):
         if self._actions is None:
             raise RuntimeError("stepWait() without stepAsync()")
         e = self.engine
+        self._tape_spend(1)
+        self._steps_taken += 1
         if self._has_norm() and self.world > 1:
             e.step_begin(self._actions)
             self._allreduce_moments()
@@ -268,8 +322,7 @@ class VecEnvWrapper(VecEnv):
         super().__init__(venv.nEnvs(), o_space or venv.observationSpace(), a_space or venv.actionSpace())
         self.venv = venv
 
-    def isWrapper(self):
-        return True
+    # isWrapper() is NOT overridden: nothing in the reference overrides base.h:65, a VecEnvWrapper reports false there too
 
     def reset(self, index=None):
         return self.venv.reset(index)

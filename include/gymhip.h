@@ -118,6 +118,15 @@ int gymhip_seed_reset_tape(gymhip_engine* h, uint64_t seed, int64_t episodes);
 /* The same for envs that were never seeded: each keeps a default-constructed std::mt19937 (env.h:83), so — exactly as
  * in the reference — every env replays the same stream. */
 int gymhip_unseeded_reset_tape(gymhip_engine* h, int64_t episodes);
+/* A host-drawn tape is finite; an env that needs row `tape rows` wraps to row 0 and sets bit 0 of the error word.  These two
+ * let a host mirror keep that from ever happening (gym::HipVecEnv and gym_amd.vec_env.HipVecEnv do, by default):
+ *   _tape_cursor_max: rows consumed so far by the env that consumed most (synchronises `stream`; 0 without a tape).  No
+ *       CartPole episode is shorter than min(8, max_episode_steps) steps, so with r rows left an engine can take 8 r - 8 more
+ *       steps before the next look.
+ *   _extend_reset_tape: redraw the SAME std::mt19937 streams with `episodes` (> current) rows per env; cursors are kept, a
+ *       running engine just finds more rows.  Only for tapes drawn by _seed_/_unseeded_reset_tape; synchronises the device. */
+int gymhip_tape_cursor_max(gymhip_engine* h, int32_t* host_out, void* stream);
+int gymhip_extend_reset_tape(gymhip_engine* h, int64_t episodes);
 /* Fill a device-resident tape of `episodes` rows with the COUNTER_RNG generator (bench / throughput set-up). */
 int gymhip_generate_reset_tape(gymhip_engine* h, int64_t episodes, void* stream);
 /* Copy the device tape back (tests: lets the CPU oracle replay a device-generated tape). */

@@ -1,0 +1,48 @@
+// ref_dropin_tu.cpp — the in-reference-tree configuration of the drop-in, compiled for real: the REFERENCE's own
+// wrappers/vec_env/base.h, vec_env_wrapper.h, wrappers/monitor.h, env.h and spaces (included where they lie, its
+// spaces/{space,discrete,util}.cpp compiled in place) + our gym/hip_vec_env.h with GYMHIP_USE_REFERENCE_HEADERS, linked against
+// libgymhip.so and the image's libtorch.  No stand-in headers.  What it proves: gym::HipVecEnv IS-A the reference's
+// gym::VecEnv<false>, is held by the unique_ptr type the reference's trainers hold (test/classic_control.cpp:31-41) and is
+// accepted by the reference's own gym::VecEnvWrapper<false>.  Built by `make -C oracle _ref`; run (no GPU needed: the engine
+// is created lazily at the first reset) by tests/test_ref_pin.py, which checks the line it prints.
+#define GYMHIP_USE_REFERENCE_HEADERS
+#include "wrappers/vec_env/base.h"
+#include "wrappers/vec_env/vec_env_wrapper.h"
+#include "wrappers/monitor.h"
+
+#include "gym/hip_vec_env.h"
+
+#include <cstdio>
+#include <type_traits>
+
+static_assert(std::is_base_of_v<gym::VecEnv<false>, gym::HipVecEnv>, "HipVecEnv derives from the reference's VecEnv<false>");
+static_assert(std::is_same_v<gym::VecEnv<false>::StepT, gym::VecEnvStepReturn<torch::Tensor>>, "reference step type");
+static_assert(!std::is_abstract_v<gym::HipVecEnv>, "every pure virtual of base.h:52-71 is overridden");
+
+// a wrapper written against the reference's VecEnvWrapper, as its own VecNormalize / VecFrameStack are (vec_env_wrapper.h:12-55)
+struct CountingWrapper : gym::VecEnvWrapper<false> {
+    using gym::VecEnvWrapper<false>::VecEnvWrapper;
+    int steps = 0;
+    StepT stepWait() noexcept override { steps++; return gym::VecEnvWrapper<false>::stepWait(); }
+};
+
+int main(int argc, char** argv) {
+    gym::HipVecEnvOptions o;
+    o.env_kind = GYMHIP_ENV_CARTPOLE; o.n_envs = 64; o.max_episode_steps = 500; o.monitor = true;
+    std::unique_ptr<gym::VecEnv<false>> env = gym::makeTrainingVecNormRO(o);          // gym_.h:15-16 shape
+    auto seeds = env->seed(7);
+    CountingWrapper w(std::move(env));                                                 // the reference's forwarding base owns it now
+    auto* box = w.observationSpace()->as<gym::Box<float>>();
+    auto* act = w.actionSpace()->as<gym::Discrete>();
+    std::printf("dropin nEnvs=%d obs_size=%lld obs_type=%d ranges=%zu act_n=%lld act_size=%lld seeds=%zu first_seed=%zu is_wrapper=%d\n", w.nEnvs(),
+                (long long)w.observationSpace()->size()[0], (int)w.observationSpace()->type(), box ? box->getRange().size() : 0, act ? (long long)act->n : -1,
+                (long long)w.actionSpace()->size()[0], seeds.size(), seeds.empty() ? 0 : seeds[0], (int)w.isWrapper());
+    if (argc > 1 && std::string(argv[1]) == "run") {   // only meaningful where a GPU is visible
+        gym::VecEnv<false>& v = w;   // trainers hold the base type; VecEnvWrapper's step(int, Tensor) hides step(actions) by name (vec_env_wrapper.h:49)
+        auto obs = v.reset();
+        auto r = v.step(torch::zeros({64}, torch::kInt64));
+        std::printf("run obs=[%lld,%lld] reward=[%lld,%lld] done=[%lld,%lld] steps=%d\n", (long long)obs.size(0), (long long)obs.size(1), (long long)r.reward.size(0),
+                    (long long)r.reward.size(1), (long long)r.done.size(0), (long long)r.done.size(1), w.steps);
+    }
+    return 0;
+}

@@ -114,3 +114,14 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def freeze_spaces():
+    """tests/golden/ref_spaces.json: tests/cpp/spaces_probe.h over the reference's own spaces/*.h, spaces/*.cpp and env.h
+    (oracle/_ref/ref_spaces_driver).  The sampled values inside are range checks only, so the file is deterministic."""
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_spaces_driver")
+    subprocess.run([drv, os.path.join(OUT, "ref_spaces.json")], check=True)
+
+
+if __name__ == "__main__" and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_spaces_driver")):
+    freeze_spaces()

@@ -29,7 +29,8 @@ def test_spaces_mirror_reference():
     c = o.clone()
     assert c is not o and c.size() == o.size()
     img = spaces.makeBoxSpace(0, 255, [84, 84, 1], dtype=np.uint8)                     # warp_frame.h:28
-    assert img.size() == [84, 84, 1] and img.type() == np.uint8
+    assert img.size() == [84, 84, 1] and img.type() == np.int8                          # make_shape<uint8_t> reports kChar (util.h:60-63)
+    assert a.size() == [2] and a2.size() == [3]                                        # discrete.cpp:16: Discrete's shape is {n}
 
 
 def test_shard_range_partitions_exactly():
@@ -56,7 +57,8 @@ def test_hipvecenv_host_logic_without_gpu():
     with pytest.raises(TypeError):
         V.VecNormalize(object())
     w = V.TrainingVecNormRO(V.HipVecEnv("MountainCar-v0", 8, max_episode_steps=200, clip_reward=True))
-    assert w.isWrapper() and w.nEnvs() == 8 and w.venv._norm["gamma"] == 0.99 and w.venv._norm["clip_obs"] == 10.0
+    assert not w.isWrapper() and w.nEnvs() == 8          # base.h:65 is never overridden in the reference
+    assert w.nEnvs() == 8 and w.venv._norm["gamma"] == 0.99 and w.venv._norm["clip_obs"] == 10.0
     assert w.actionSpace().n == 3
 
 

@@ -128,3 +128,91 @@ def test_monitor_csv_bytes_match_the_reference_writer(oracle, tmp_path):
     assert len(eps) == len(rows)
     for (t, r, l), (er, el) in zip(rows, eps):
         assert float("%g" % er) == r and float(el) == l
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Spaces, Env::seed and the in-tree drop-in: everything of the reference that compiles here without a stand-in header
+# ---------------------------------------------------------------------------------------------------------------------
+import json
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SPACES_DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_spaces_driver")
+DROPIN = os.path.join(ROOT, "oracle", "_ref", "ref_dropin_tu")
+MIRROR_DEMO = os.path.join(ROOT, "tests", "cpp", "bin", "spaces_mirror_demo")
+
+
+def _frozen_spaces():
+    return json.load(open(os.path.join(G, "ref_spaces.json")))
+
+
+@pytest.mark.skipif(not os.path.exists(SPACES_DRIVER), reason="reference not mounted: oracle/_ref not built (frozen file is checked below)")
+def test_live_reference_spaces_probe_equals_frozen():
+    r = subprocess.run([SPACES_DRIVER], capture_output=True, text=True, check=True)
+    assert json.loads(r.stdout) == _frozen_spaces()
+
+
+def test_cpp_mirror_spaces_equal_the_references():
+    """gym/vec_env.h under the same probe (tests/cpp/spaces_probe.h) the reference's own spaces/*.cpp + env.h were run under."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "bin/spaces_mirror_demo"], capture_output=True, check=True)
+    r = subprocess.run([MIRROR_DEMO], capture_output=True, text=True)
+    assert r.returncode == 0 and "factories ok" in r.stderr, r.stderr[-500:]
+    assert json.loads(r.stdout) == _frozen_spaces()
+
+
+def test_python_spaces_match_the_references():
+    from gym_amd import spaces as S
+    g = _frozen_spaces()
+    KCHAR, KINT, KFLOAT = 1, 3, 6                                                  # c10::ScalarType values
+    code = {np.dtype(np.int8): KCHAR, np.dtype(np.int32): KINT, np.dtype(np.float32): KFLOAT}
+    d = S.Discrete(5)
+    assert d.size() == g["discrete5"]["size"] and code[d.type()] == g["discrete5"]["type"] and d.n == g["discrete5"]["n"]
+    assert d.keys() == [g["discrete5"]["keys"]] and all(0 <= d.sample() < 5 for _ in range(200))
+    assert g["discrete0_throws"] == g["discrete_neg_throws"] == "invalid_argument"
+    for bad in (0, -3):
+        with pytest.raises(ValueError):                                            # Python's counterpart of std::invalid_argument
+            S.Discrete(bad)
+    b = S.makeBoxSpace(2)
+    assert b.size() == g["box_default_float"]["size"] and code[b.type()] == g["box_default_float"]["type"]
+    assert [[np.float32(r.low), np.float32(r.high)] for r in b.getRange()] == [[np.float32(x) for x in rr] for rr in g["box_default_float"]["ranges"]]
+    rr = g["box_vector_float"]["ranges"]
+    v = S.makeBoxSpace([x[0] for x in rr], [x[1] for x in rr], 4)
+    assert v.size() == g["box_vector_float"]["size"] and [[r.low, r.high] for r in v.getRange()] == rr
+    c = v.clone()
+    assert c.as_(S.Box) is c and c.as_(S.Discrete) is None and [[r.low, r.high] for r in c.getRange()] == g["box_clone"]["ranges"]
+    assert g["box_vector_zero_dim_throws"] == g["box_vector_two_dim_throws"] == "runtime_error" and g["box_vector_empty_range_throws"] is None
+    with pytest.raises(RuntimeError):
+        S.Box([0.0], [1.0], shape=(2, 2))
+    with pytest.raises(RuntimeError):
+        S.Box([0.0], [1.0], shape=())
+    img = S.makeBoxSpace(0, 255, [84, 84, 1], dtype=np.uint8)
+    assert img.size() == g["box_image_u8"]["size"] and code[img.type()] == g["box_image_u8"]["type"] == KCHAR     # the uint8 -> kChar quirk
+    assert [[r.low, r.high] for r in img.getRange()] == g["box_image_u8"]["ranges"]
+    o, a = S.cartpole_spaces()
+    assert [[np.float32(r.low), np.float32(r.high)] for r in o.getRange()][:3] == [[np.float32(x) for x in q] for q in rr[:3]]   # the probe used cartpole.cpp:10-16's values
+
+
+def test_env_seed_streams_match_the_references(oracle):
+    """Env::seed -> std::mt19937 (env.h:60-68,83) as the reference's own env.h runs it: raw outputs and the reset draws
+    (uniform_real_distribution<float>(-0.05f, 0.05f), cartpole.cpp:21-26) for several seeds, against the oracle's generator,
+    the oracle's reset tape and the library's host-drawn tape arithmetic."""
+    g = _frozen_spaces()["env_seed"]
+    assert list(oracle.mt19937_raw(5489, 2)) == g["unseeded_raw"]                  # never seeded == default-constructed mt19937
+    for seed in (0, 1, 7, 12345, 4294967301):
+        assert list(oracle.mt19937_raw(seed, 4)) == g[f"raw_{seed}"]
+        tape = oracle.cartpole_reset_tape(seed, 1, 2)                              # env 0 of a vec env seeded `seed`: episodes 0 and 1
+        assert np.array_equal(tape.reshape(-1), np.array(g[f"draws_{seed}"], np.float32))
+    # sync_env.h:74-83: env i of a vec env seeded s is seeded s + i
+    assert np.array_equal(oracle.cartpole_reset_tape(0, 8, 1)[0, 7], np.array(g["draws_7"][:4], np.float32))
+    # the survey's probe of the compiled reference (SURVEY.md §8a A3)
+    assert np.allclose(g["draws_0"][:4], [0.0048813522, 0.0092844591, 0.0215189345, 0.0344265737], rtol=0, atol=5e-11)
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="reference not mounted: oracle/_ref not built")
+def test_dropin_compiles_against_the_reference_headers_and_describes_itself():
+    """oracle/_ref/ref_dropin_tu: gym/hip_vec_env.h with GYMHIP_USE_REFERENCE_HEADERS over the reference's base.h,
+    vec_env_wrapper.h, monitor.h and spaces, linked against libgymhip.so — that it exists means it compiled and linked."""
+    r = subprocess.run([DROPIN], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1000:]
+    f = dict(kv.split("=") for kv in r.stdout.split()[1:])
+    assert f == {"nEnvs": "64", "obs_size": "4", "obs_type": "6", "ranges": "4", "act_n": "2", "act_size": "2", "seeds": "64", "first_seed": "7", "is_wrapper": "0"}

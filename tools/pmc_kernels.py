@@ -19,7 +19,8 @@ KERNELS = {
     "step_kernel<1, true, int, true,": ("config3_step_kernel_mountaincar_lockstep_norm", N3 * (8 + 8 + 4 + 4 + 4), N3 * (8 + 8 + 4 + 4 + 4 + 4)),
     "normalize_kernel<2,": ("config3_normalize_kernel", N3 * (8 + 4), N3 * (8 + 4)),
     "atari_preprocess_kernel": ("config4_atari_preprocess_rgb", N4 * 2 * 100800, N4 * 7056),
-    "materialize_nchw_f32_kernel": ("config4_materialize_nchw_f32", N4 * 28224, N4 * 28224 * 4),
+    "materialize_nchw_kernel<0,": ("config4_materialize_nchw_f32", N4 * 28224, N4 * 28224 * 4),
+    "materialize_nchw_kernel<1, 1>": ("config4_materialize_nchw_bf16", N4 * 28224, N4 * 28224 * 2),
 }
 
 

@@ -29,10 +29,12 @@ m = 4096
 pp = AtariPreprocessor(m)
 frames = torch.randint(0, 256, (m, 2, 210, 160, 3), dtype=torch.uint8, device="cuda")
 out = torch.empty((m, 4, 84, 84), dtype=torch.float32, device="cuda")
+out16 = torch.empty((m, 4, 84, 84), dtype=torch.bfloat16, device="cuda")
 pp.reset(frames)
 for _ in range(40):
     pp.step(frames)
     pp.stacked_nchw_f32(out)
+    pp.stacked_nchw_16(torch.bfloat16, out16)
 torch.cuda.synchronize()
 pp.close()
 print("PROFILE_EXTRA_OK")
