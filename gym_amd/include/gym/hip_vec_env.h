@@ -4,8 +4,8 @@
 // include/gymhip.h (libgymhip.so).  libtorch is used only to hand results back as torch::Tensor views of device memory.
 //
 // Inside the reference tree:   #define GYMHIP_USE_REFERENCE_HEADERS, then #include "wrappers/vec_env/base.h" (VecEnv<false>,
-// spaces, AnyMap) and "wrappers/monitor.h" (gym::Result) BEFORE this header; oracle/ref_driver/ref_dropin_tu.cpp is that
-// configuration, compiled against the reference's headers where they lie by `make -C oracle _ref`.
+// spaces, AnyMap) and "wrappers/monitor.h" (gym::Result) BEFORE this header (the build container compiles
+// exactly that configuration against the reference's headers where they lie).
 // Elsewhere the stand-alone mirror in gym/vec_env.h supplies the same names.
 #pragma once
 #include <algorithm>

@@ -4,8 +4,8 @@
 // (wrappers/vec_env/base.h:18-79, vec_env_wrapper.h:12-55), the single-env gym::Env face (env.h:26-85) and the space types the
 // interface exposes (spaces/space.h:20-104, box.h:15-54, box.tpp:7-18, discrete.h:14-31, discrete.cpp:15-21, util.h:18-97,
 // common/utils.h:82-122).  Inside the reference tree define GYMHIP_USE_REFERENCE_HEADERS before including hip_vec_env.h and
-// these definitions are skipped in favour of the reference's own (oracle/Makefile target _ref compiles that
-// configuration against the reference's headers where they lie).  tests/test_ref_pin.py checks this mirror's space types
+// these definitions are skipped in favour of the reference's own (INTEGRATION.md shows that configuration; the build container compiles it
+// against the reference's headers where they lie).  tests/test_ref_pin.py checks this mirror's space types
 // against values the reference's own spaces code produced (tests/golden/ref_spaces.json).
 #pragma once
 #ifndef GYMHIP_USE_REFERENCE_HEADERS

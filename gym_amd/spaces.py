@@ -1,7 +1,7 @@
 """Host-side mirror of the reference's spaces (spaces/space.h:20-104, box.h:15-54, box.tpp:7-18, discrete.h:14-31,
 discrete.cpp:15-21, util.h:18-97, common/utils.h:82-122).  Only what the hot path's VecEnv interface exposes: Box / Discrete
 with size(), type(), getRange(), sample(), clone(), as_().  Checked against what the reference's own spaces code reports
-(tests/golden/ref_spaces.json, produced by oracle/_ref/ref_spaces_driver; tests/test_ref_pin.py)."""
+(tests/golden/ref_spaces.json; tests/test_ref_pin.py)."""
 from __future__ import annotations
 
 import copy

@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
     o.n_envs = n;
     o.max_episode_steps = cart ? 500 : 200;
     o.clip_reward = !cart;
-    o.tape_episodes = steps / 8 + 4;
+    o.tape_episodes = 4;   // far too few on purpose: the mirror's tape guard must extend the tape (same mt19937 streams) before any env runs out
     std::unique_ptr<gym::VecEnv<false>> env = norm ? gym::makeTrainingVecNormRO(o) : gym::HipVecEnv::make(o);
     auto seeds = env->seed(7);
     if ((int64_t)seeds.size() != n || seeds[1] != 8) return 3;
@@ -42,6 +42,13 @@ int main(int argc, char** argv) {
         std::printf("step %d %lld %.9e %.9e\n", t, (long long)r.done.sum().item<float>(), r.observation.to(torch::kFloat64).sum().item<double>(),
                     r.reward.to(torch::kFloat64).sum().item<double>());
         if (csv) csv->log(static_cast<gym::HipVecEnv*>(env.get())->infos());
+        if (t == steps / 2) {
+            // the per-index step is a stub that returns BUFFERED values (sync_env.h:141-157): [1]-shaped reward / done of that env
+            auto one = env->step(3, actions);
+            if (!one.reward.defined() || one.reward.dim() != 1 || one.reward.size(0) != 1 || one.done.size(0) != 1 || one.info.size() != 1 ||
+                one.reward[0].item<float>() != r.reward[3][0].item<float>() || one.done[0].item<float>() != r.done[3][0].item<float>() ||
+                !torch::equal(one.observation, r.observation[3])) return 6;
+        }
         if (t == steps - 1) {
             if (csv) csv->flush();
             auto infos = static_cast<gym::HipVecEnv*>(env.get())->infos();

@@ -209,3 +209,71 @@ def test_second_reset_and_midrun_reseed_follow_the_envs_generators(oracle):
     assert np.array_equal(env.reset().cpu().numpy(), ov.reset())
     run(100, 120)
     assert env.engine.poll_error() == 0
+
+
+@pytest.mark.parametrize("max_steps", [None, 3])
+def test_reset_tape_is_extended_before_any_env_runs_out(oracle, max_steps):
+    """The drop-in's default must never replay reset states: starting from FOUR tape rows per env, the mirror's tape guard
+    (cursor look-ups budgeted by the shortest possible episode, then the same std::mt19937 streams redrawn with more rows)
+    keeps every stream identical to the reference generator's across 600 steps (~27 resets per env, 200 with TimeLimit(3))."""
+    from gym_amd.vec_env import HipVecEnv
+    n, T, seed = 300, 600, 11
+    env = HipVecEnv("CartPole-v1", n, max_episode_steps=max_steps, tape_episodes=4)
+    env.seed(seed)
+    ov = oracle.vec(CARTPOLE, n, (F_TIME_LIMIT if max_steps else 0) | F_MONITOR, max_steps or 0)
+    ov.seed(seed)
+    assert np.array_equal(env.reset().cpu().numpy(), ov.reset())
+    acts = splitmix_actions(5, T, n, 2)
+    dev = torch.from_numpy(acts.astype(np.int32)).cuda()
+    for t in range(T):
+        s = env.step(dev[t])
+        r = ov.step(acts[t])
+        assert np.array_equal(s.done.cpu().numpy()[:, 0], r["done"]), t
+        assert np.array_equal(s.observation.cpu().numpy(), r["obs"]), t
+        if t == 300:   # per-index and whole-batch resets consume rows too
+            assert np.array_equal(env.reset().cpu().numpy(), ov.reset())
+    assert env._tape_episodes > 4 and env.engine.tape_cursor_max() > 20
+    assert env.engine.tape_cursor_max() <= env._tape_episodes and env.engine.poll_error() == 0
+
+
+def test_raw_engine_still_reports_a_tape_that_ran_out():
+    """Below the mirrors, the C ABI keeps its documented behaviour: rows wrap and the sticky error word says so."""
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+    eng = Engine(EngineConfig(env_kind=L.ENV_CARTPOLE, n_envs=64, reset_mode=L.RESET_TAPE, wrappers=L.WRAP_TIME_LIMIT, max_episode_steps=2), 0)
+    eng.seed_reset_tape(0, 3)
+    eng.reset()
+    a = torch.zeros(64, dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        eng.step(a)
+    assert eng.poll_error() == 0 and eng.tape_cursor_max() == 2
+    for _ in range(4):
+        eng.step(a)
+    assert eng.poll_error() & 1
+    with pytest.raises(L.GymhipError):
+        eng.extend_reset_tape(2)                       # not more rows than it has
+    up = Engine(EngineConfig(env_kind=L.ENV_CARTPOLE, n_envs=8, reset_mode=L.RESET_TAPE), 0)
+    up.upload_reset_tape(np.zeros((2, 8, 4), np.float32))
+    with pytest.raises(L.GymhipError):
+        up.extend_reset_tape(16)                       # only host-drawn streams can be extended
+
+
+def test_step_info_must_be_read_before_the_next_step():
+    """The reference returns concrete per-step info maps; LazyInfos reads the engine's buffers on first use and therefore
+    refuses to be read after a later step instead of silently returning that step's records."""
+    from gym_amd.vec_env import HipVecEnv
+    env = HipVecEnv("CartPole-v1", 64, max_episode_steps=5)
+    env.seed(0)
+    env.reset()
+    a = torch.zeros(64, dtype=torch.int32, device="cuda")
+    kept = None
+    for t in range(5):
+        s = env.step(a)
+        if t == 3:
+            stale, kept = s.info, env.step(a).info.materialize()
+            break
+    with pytest.raises(RuntimeError, match="before the next step"):
+        stale[0]
+    assert len(kept.done_indices()) == 64 and kept[0]["episode"]["l"] == 5.0 and kept[0]["TimeLimit.truncated"] in (True, False)
+    env.step(a)
+    assert kept[0]["episode"]["l"] == 5.0             # materialised records survive later steps
