@@ -110,6 +110,8 @@ public:
     AtariFrontEnd& operator=(const AtariFrontEnd&) = delete;
 
     int64_t nEnvs() const { return n; }
+    // VecEnv::seed (sync_env.h:74-83 -> env.h:60-63): env i's NOOP-reset generator restarts from seed + i
+    void seed(uint64_t s) { opt.seed = s; for (int64_t i = 0; i < n; i++) envs[i].rng.seed(s + (uint64_t)i); }
     // VecNormAndPermute(VecFrameStack(...)) observation of the last reset()/step(): device f32 [N][n_stack][dst_h][dst_w], ready on `stream`
     const float* observation() const { return dev_obs; }
     // the engine behind it, e.g. for gymhip_atari_materialize_nchw_16(preprocessor(), out, GYMHIP_OUT_BF16, stream) when the policy runs in half precision

@@ -31,6 +31,12 @@ int main(int argc, char** argv) {
     ncclComm_t comm;
     int dev = 0;
     CHECK_NCCL(ncclCommInitAll(&comm, 1, &dev));
+    // the communicator must report the size it was given: on an N-GPU run this line is what shows N ranks in the log
+    int comm_ranks = -1, comm_rank = -1;
+    CHECK_NCCL(ncclCommCount(comm, &comm_ranks));
+    CHECK_NCCL(ncclCommUserRank(comm, &comm_rank));
+    std::printf("rccl_comm ranks %d rank %d\n", comm_ranks, comm_rank);
+    if (comm_ranks != 1 || comm_rank != 0) { std::fprintf(stderr, "RCCL reports %d ranks (rank %d), expected the 1 it was created with\n", comm_ranks, comm_rank); return 5; }
 
     gymhip_config c;
     std::memset(&c, 0, sizeof c);

@@ -94,16 +94,31 @@ def _fake_palette():
     return np.array([0 if k & 1 else mix(77 + k) & 0xFFFFFF for k in range(256)], np.uint32)
 
 
+VE_BIN = os.path.join(ROOT, "tests", "cpp", "bin", "hip_atari_vec_env_demo")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("life_loss,fire", [(True, False), (False, True)])
+def test_hip_atari_vec_env_is_a_vecenv_and_matches_the_reference_chain(oracle, tmp_path, life_loss, fire):
+    """gym::HipAtariVecEnv<Emu> : gym::VecEnv<false> — the Atari stack held the way the reference's trainer holds it
+    (unique_ptr<VecEnv<false>>, test/atari_env.cpp:48-60) and driven only through the base-class interface (seed / reset /
+    step(actions) / step(index, .) / spaces): observation [N,4,84,84] f32 on the GPU, reward / done [N,1] f32, info maps with
+    "ale.lives" and "episode" — against the oracle's restatement of AtariWrapper::make + SyncVecEnv + VecFrameStack +
+    VecNormAndPermute over the scripted emulator."""
+    test_atari_front_end_matches_the_reference_chain(oracle, tmp_path, life_loss, fire, exe=VE_BIN)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("life_loss,fire", [(True, False), (True, True), (False, True)])
-def test_atari_front_end_matches_the_reference_chain(oracle, tmp_path, life_loss, fire):
+def test_atari_front_end_matches_the_reference_chain(oracle, tmp_path, life_loss, fire, exe=None):
     """(f4) gym::AtariFrontEnd — NOOP / MaxAndSkip / Monitor / EpisodicLife / FireReset control flow on the host, pinned
     double-buffered upload of palette-index screens, colour + max + warp + frame stack + permute on the GPU — against the
     oracle's class-by-class restatement of AtariWrapper::make under SyncVecEnv auto-reset, over a scripted emulator."""
-    assert os.path.exists(FE_BIN), "build tests/cpp first"
+    exe = exe or FE_BIN
+    assert os.path.exists(exe), "build tests/cpp first"
     n, T, seed = 6, 90, 4
     out = tmp_path / "fe.bin"
-    r = subprocess.run([FE_BIN, str(n), str(T), str(seed), str(int(life_loss)), str(int(fire)), str(out)], capture_output=True, text=True, timeout=240)
+    r = subprocess.run([exe, str(n), str(T), str(seed), str(int(life_loss)), str(int(fire)), str(out)], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stderr[-2000:])
     raw = np.fromfile(out, np.uint8)
     assert tuple(raw[:16].view(np.int64)) == (n, T)
@@ -146,6 +161,8 @@ def test_cpp_rccl_allreduce_binding_on_the_moments_buffer():
     n, T = 30000, 40
     r = subprocess.run([exe, str(n), str(T)], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    comm = [l for l in r.stdout.strip().splitlines() if l.startswith("rccl_comm")][-1]
+    assert comm.split() == ["rccl_comm", "ranks", "1", "rank", "0"]                              # RCCL reports the communicator size it was given
     line = [l for l in r.stdout.strip().splitlines() if l.startswith("rccl_identical")][-1]   # RCCL may print banners of its own
     tag, same, _, steps, _, count = line.split()
     assert same == "1" and int(steps) == T
