@@ -48,7 +48,7 @@ def max_over_ranks(torch, dist, dt):
     return float(t.item())
 
 
-PREWARM_SECONDS = 0.3   # untimed, before the caller's --warmup: clocks ramp on wall time, not on a step count
+PREWARM_SECONDS = float(os.environ.get("GYM_BENCH_PREWARM_S", "0.3"))   # untimed, before the caller's --warmup: clocks ramp on wall time, not on a step count (0 for counter-collection passes: tools/profile_r02.sh)
 
 
 def prewarm(torch, eng, actions, max_steps=None, seconds=PREWARM_SECONDS):

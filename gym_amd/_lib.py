@@ -16,6 +16,7 @@ PRECISION_LOCKSTEP_F64, PRECISION_F32 = 0, 1
 RESET_TAPE, RESET_COUNTER_RNG = 0, 1
 WRAP_TIME_LIMIT, WRAP_CLIP_REWARD, WRAP_MONITOR = 1, 2, 4
 WRAP_NORM_OBS, WRAP_NORM_REWARD, WRAP_NORM_TRAINING = 8, 16, 32
+WRAP_NO_AUTO_RESET = 64
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
 OUT_F16, OUT_BF16 = 0, 1
 NOALLOC_MAX_ROWS = 1 << 26

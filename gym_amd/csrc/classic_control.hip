@@ -52,7 +52,8 @@ namespace {
 #endif
 constexpr int kBlock = GYMHIP_BLOCK;   // 512: equal to 256 on the headline kernel, best on the normaliser pair (profiles/r02_sweep_block.txt)
 constexpr int kMaxGrid = 8192;  // upper bound of the grid-stride launch (sizes the per-block partial buffers)
-constexpr int kDefaultGrid = 512;   // 256 CUs x 2 blocks of 512 threads: best of the sweeps (profiles/r01_sweep.txt, r02_sweep_block.txt); GYMHIP_GRID overrides
+constexpr int kDefaultGrid = 512;   // 256 CUs x 2 blocks of 512 threads: best for the float-state and MountainCar kernels and for normaliser engines (fewer partial rows to fold); GYMHIP_GRID overrides
+constexpr int kPlainGrid = 2048;    // CartPole lockstep without the normaliser (the 84-B kernel): 1024 .. 4096 measure alike, 1.5 % above 512 (profiles/r02_sweeps.txt)
 constexpr size_t kNtFootprint = (size_t)336 << 20;   // bytes; see gymhip_create
 constexpr int kMaxCols = 16;    // >= 2F+6 for F=4
 
@@ -469,6 +470,7 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
     const bool clip = p.wrappers & GYMHIP_WRAP_CLIP_REWARD;
     const bool tape_mode = KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE;
     const bool ret_lane = (p.wrappers & GYMHIP_WRAP_NORM_REWARD) && (p.wrappers & GYMHIP_WRAP_NORM_TRAINING);
+    const bool auto_reset = !(p.wrappers & GYMHIP_WRAP_NO_AUTO_RESET);   // sync_env.h:28,92
 
     // Everything one env-step reads, as raw registers: the loads are issued as a batch and nothing depends on them
     // until the next iteration's dynamics start.
@@ -479,8 +481,8 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
         uint32_t w;       // packed step counter / episode record / tape cursor (gymhip.h)
         float ret;
     };
-    // `i` must be a valid env index: the loads are unconditional so that the compiler can count them (a lane with no
-    // next iteration re-reads its own, cached, inputs and discards them).
+    // `i` must be a valid env index.  A lane with no next iteration issues no loads (an earlier form re-read the lane's own
+    // inputs unconditionally: one wasted 40-B read per THREAD per launch, 5 % of the fetch traffic at 2048 x 512 threads).
     auto issue_loads = [&](int64_t i, Inputs& in) {
         load_obs<NT>(b.obs, i, in.o);
         if constexpr (LOCKSTEP) load_i32<NT>((const int32_t*)b.state, i, in.k);
@@ -497,10 +499,10 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     Inputs cur, nxt;
-    issue_loads(i < p.n ? i : p.n - 1, cur);
+    if (i < p.n) issue_loads(i, cur);
     for (; i < p.n; i += stride) {
 #if GYMHIP_PIPE
-        issue_loads(i + stride < p.n ? i + stride : i, nxt);
+        if (i + stride < p.n) issue_loads(i + stride, nxt);
 #else
         if (i != (int64_t)blockIdx.x * kBlock + threadIdx.x) issue_loads(i, cur);
 #endif
@@ -516,29 +518,37 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
         int t = CounterWord<KIND>::steps_now(w);
         uint32_t cursor = CounterWord<KIND>::cursor(w);
 
-        bool env_done;
-        if constexpr (KIND == KIND_CARTPOLE) env_done = cartpole_step(s, action, t); else env_done = mountaincar_step(s, action);
-        t += 1;
+        // auto_reset off: an env that finished and has not been reset (gymhip_reset_index) is frozen — stepping it is the
+        // misuse the reference reports on stderr (monitor.h:75-77); state and record stay, reward 0, done 1, error bit 3
+        const bool frozen = !auto_reset && (w >> 31);
+        bool env_done = false;
+        if (!frozen) {
+            if constexpr (KIND == KIND_CARTPOLE) env_done = cartpole_step(s, action, t); else env_done = mountaincar_step(s, action);
+            t += 1;
+        }
         bool done = env_done, trunc = false;
         if (time_limit && t >= p.max_episode_steps) { trunc = !env_done; done = true; }   // time_limit.h:30-34
         float reward = EnvTraits<KIND>::step_reward;
         if (clip) reward = reward == 0.f ? reward : (reward > 0.f ? 1.f : -1.f);           // clip_reward.h:22-24
+        if (frozen) { atomicOr(p.error_flag, 8); t = CounterWord<KIND>::steps_field(w); done = true; trunc = (w >> 30) & 1u; reward = 0.f; }
 
-        if (done) {
+        if (done && !frozen) {
             // Monitor (monitor.h:78-97): every step of these envs pays the same reward, so the ordered float sum
             // of t copies equals float(t)*reward exactly (t < 2^24).  The finished episode's (length, truncated)
             // and the reset-tape cursor live in the counter word, which is rewritten every step anyway: no extra
             // HBM traffic and no scattered read-modify-write on the done path.
             ep[0] += 1.0; ep[1] += (double)((float)t * reward); ep[2] += (double)t;
-            int64_t e;
-            if (tape_mode) {
-                e = cursor;
-                if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
-                cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
-            } else {
-                e = p.step_counter;            // stateless: (seed, env, global step) is unique per reset
+            if (auto_reset) {                  // sync_env.h:92-100: terminal obs replaced by the reset obs (else: kept, no draw consumed)
+                int64_t e;
+                if (tape_mode) {
+                    e = cursor;
+                    if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
+                    cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
+                } else {
+                    e = p.step_counter;        // stateless: (seed, env, global step) is unique per reset
+                }
+                reset_state<KIND, T>(p, i, e, s);
             }
-            reset_state<KIND, T>(p, i, e, s);   // sync_env.h:92-100: terminal obs replaced by the reset obs
         }
 
         float o[F];
@@ -975,8 +985,8 @@ bool valid_config(const gymhip_config* c) {
     return true;
 }
 
-int grid_for(int64_t n) {
-    int64_t cap = kDefaultGrid;
+int grid_for(int64_t n, bool norm, bool cartpole_lockstep) {
+    int64_t cap = (!norm && cartpole_lockstep) ? kPlainGrid : kDefaultGrid;
     if (const char* e = getenv("GYMHIP_GRID")) { int v = atoi(e); if (v > 0 && v <= kMaxGrid) return (int)std::min<int64_t>(v, (n + kBlock - 1) / kBlock); }
     // One env per thread until every CU has a block (256); then up to 8 envs per thread before the grid grows to its cap: at
     // the 131,072 .. 1 M envs per GPU of BASELINE configs[2] fewer blocks mean fewer partial rows for the normalise kernel to fold.
@@ -1215,8 +1225,8 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
     h->device = device;
     h->F = obs_dim_of(cfg->env_kind);
     h->L = make_layout(*cfg);
-    h->grid = grid_for(cfg->n_envs);
     h->norm = cfg->wrappers & (GYMHIP_WRAP_NORM_OBS | GYMHIP_WRAP_NORM_REWARD);
+    h->grid = grid_for(cfg->n_envs, h->norm, cfg->env_kind == KIND_CARTPOLE && cfg->precision == GYMHIP_PRECISION_LOCKSTEP_F64);
     h->stats_slot = 0;
     h->tape = nullptr; h->tape_episodes = 0; h->tape_source = 0; h->tape_seeded = false; h->tape_seed = 0;
     h->did_reset = false; h->pending_finish = false; h->pending_is_reset = false;
@@ -1455,6 +1465,7 @@ int gymhip_rollout(gymhip_engine* h, const uint8_t* action_tape, int64_t k_steps
     if (int rc = check_handle(h)) return rc;
     if (!action_tape || k_steps <= 0) return fail(GYMHIP_EINVAL, "action_tape null or k_steps <= 0");
     if (h->norm) return fail(GYMHIP_EINVAL, "rollout is not available with the normaliser (needs a grid-wide reduction per step)");
+    if (h->cfg.wrappers & GYMHIP_WRAP_NO_AUTO_RESET) return fail(GYMHIP_EINVAL, "rollout always auto-resets: not available with GYMHIP_WRAP_NO_AUTO_RESET");
     if (!h->did_reset) return fail(GYMHIP_ESTATE, "rollout before reset");
     hipStream_t s = (hipStream_t)stream;
     StepParams p = make_params(h);

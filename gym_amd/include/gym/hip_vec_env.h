@@ -35,6 +35,8 @@ struct HipVecEnvOptions {
     int max_episode_steps = 0;                // TimeLimit (time_limit.h:22-26); 0 = no TimeLimit wrapper
     bool clip_reward = false;                 // ClipRewardEnv
     bool monitor = true;                      // Monitor
+    bool auto_reset = true;                   // SyncVecEnv(envs, auto_reset) (sync_env.h:28,44,92): false = a finished env keeps its terminal
+                                              // observation and waits for reset(index)
     bool lockstep = true;                     // reference-exact arithmetic (double state); false = float-state throughput mode
     bool host_drawn_resets = true;            // std::mt19937 reset tape (reference-exact); false = stateless counter RNG
     int64_t tape_episodes = 0;                // reset-tape rows per env to start with; 0 = at most 256 MiB of rows, 8..2048 per env.
@@ -236,7 +238,8 @@ private:
         auto flag = [](bool on, uint32_t bit) { return on ? bit : 0u; };
         c.wrappers = flag(opt.max_episode_steps > 0, GYMHIP_WRAP_TIME_LIMIT) | flag(opt.clip_reward, GYMHIP_WRAP_CLIP_REWARD) |
                      flag(opt.monitor, GYMHIP_WRAP_MONITOR) | flag(opt.norm_obs, GYMHIP_WRAP_NORM_OBS) |
-                     flag(opt.norm_reward, GYMHIP_WRAP_NORM_REWARD) | flag(opt.training, GYMHIP_WRAP_NORM_TRAINING);
+                     flag(opt.norm_reward, GYMHIP_WRAP_NORM_REWARD) | flag(opt.training, GYMHIP_WRAP_NORM_TRAINING) |
+                     flag(!opt.auto_reset, GYMHIP_WRAP_NO_AUTO_RESET);
         c.max_episode_steps = opt.max_episode_steps;
         c.n_envs = opt.n_envs; c.env_offset = opt.env_offset; c.seed = seeded ? seed_value : 0;
         c.clip_obs = opt.clip_obs; c.clip_reward = opt.clip_rew; c.gamma = opt.gamma; c.epsilon = opt.epsilon;

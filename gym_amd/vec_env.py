@@ -161,8 +161,7 @@ class HipVecEnv(VecEnv):
                  rank: int | None = None, world: int | None = None, process_group=None, auto_reset: bool = True):
         if env_id not in _ENV_IDS:
             raise ValueError(f"unknown env id {env_id!r}; the engine implements {sorted(_ENV_IDS)}")
-        if not auto_reset:
-            raise ValueError("the fused kernel always auto-resets (SyncVecEnv's default, sync_env.h:28,92); auto_reset=False is not implemented")
+        self._auto_reset = bool(auto_reset)   # SyncVecEnv(envs, auto_reset) (sync_env.h:28,44): off = finished envs wait for reset(index)
         self.kind = _ENV_IDS[env_id]
         self.rank = int(os.environ.get("RANK", 0)) if rank is None else rank
         self.world = int(os.environ.get("WORLD_SIZE", 1)) if world is None else world
@@ -172,7 +171,8 @@ class HipVecEnv(VecEnv):
         o_space, a_space = spaces.cartpole_spaces() if self.kind == L.ENV_CARTPOLE else spaces.mountaincar_spaces()
         super().__init__(hi - lo, o_space, a_space)
         self.env_offset = lo
-        self._wrappers = (L.WRAP_TIME_LIMIT if max_episode_steps else 0) | (L.WRAP_CLIP_REWARD if clip_reward else 0) | (L.WRAP_MONITOR if monitor else 0)
+        self._wrappers = ((L.WRAP_TIME_LIMIT if max_episode_steps else 0) | (L.WRAP_CLIP_REWARD if clip_reward else 0) | (L.WRAP_MONITOR if monitor else 0) |
+                          (0 if auto_reset else L.WRAP_NO_AUTO_RESET))
         self._max_steps = int(max_episode_steps or 0)
         self._lockstep = lockstep
         self._reset_mode = L.RESET_TAPE if (reset_mode == "tape" and self.kind == L.ENV_CARTPOLE) else L.RESET_COUNTER_RNG

@@ -39,7 +39,12 @@ enum {
     GYMHIP_WRAP_MONITOR = 4u,
     GYMHIP_WRAP_NORM_OBS = 8u,
     GYMHIP_WRAP_NORM_REWARD = 16u,
-    GYMHIP_WRAP_NORM_TRAINING = 32u /* isTraining: update running stats every reset/step */
+    GYMHIP_WRAP_NORM_TRAINING = 32u, /* isTraining: update running stats every reset/step */
+    /* SyncVecEnv(envs, auto_reset = false) (sync_env.h:28,44,92): a finished env is NOT reset; its terminal observation
+     * is returned and it waits for gymhip_reset_index().  Stepping it before that reset is the misuse the reference's
+     * Monitor reports on stderr ("Tried to step environment that needs reset", monitor.h:75-77): here the env stays
+     * frozen (observation kept, reward 0, done 1) and bit 3 of the error word is set. */
+    GYMHIP_WRAP_NO_AUTO_RESET = 64u
 };
 enum { GYMHIP_ACT_I32 = 0, GYMHIP_ACT_I64 = 1, GYMHIP_ACT_U8 = 2 };
 /* Width S of the step field in the packed counter word (gymhip_buffers.counter).  A CartPole episode never exceeds
@@ -169,7 +174,8 @@ int gymhip_read_state_f64(gymhip_engine* h, double* state_out, void* stream);
 int gymhip_episode_stats(gymhip_engine* h, double* host_out, void* stream);
 /* Sticky device error word: bit0 = reset tape exhausted (an env needed more episodes than were uploaded; rows wrap),
  * bit1 = an env's tape-cursor field overflowed (2^20 episodes), bit2 = a LOCKSTEP state value left the split-double
- * range (non-finite, or nonzero below 2^-126 — the dynamics never produce either). */
+ * range (non-finite, or nonzero below 2^-126 — the dynamics never produce either), bit3 = with GYMHIP_WRAP_NO_AUTO_RESET a
+ * finished env was stepped again before its gymhip_reset_index(). */
 int gymhip_poll_error(gymhip_engine* h, int32_t* host_out, void* stream);
 
 /* VecEnv::reset(int index) (base.h:54; sync_env.h:128-139) under VecNormalize::reset(int index) (vec_normalize.h:179-189):

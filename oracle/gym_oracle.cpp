@@ -236,6 +236,7 @@ enum Flags { F_TIME_LIMIT = 1, F_CLIP_REWARD = 2, F_MONITOR = 4 };
 struct VecEnv {
     std::vector<std::unique_ptr<Env>> envs;
     int F = 0; int threads = 1;
+    bool auto_reset = true;      // SyncVecEnv's m_AutoReset (sync_env.h:28,44,92)
     int64_t n() const { return (int64_t)envs.size(); }
     void seed(uint64_t s) { for (size_t i = 0; i < envs.size(); i++) envs[i]->seed(s + i); }  // sync_env.h:74-83
     void reset(float* obs, double* obs64) {
@@ -251,7 +252,7 @@ struct VecEnv {
         for (int64_t i = 0; i < n(); i++) {
             double o[8];
             StepOut r = envs[i]->step(act[i], o);         // sync_env.h:91
-            if (r.done) envs[i]->reset(o);                // :92-100 (m_AutoReset)
+            if (r.done && auto_reset) envs[i]->reset(o);  // :92-100 (m_AutoReset); otherwise the terminal observation is returned
             rew[i] = r.reward; done[i] = r.done ? 1.f : 0.f;          // :102-103
             if (trunc) trunc[i] = (r.has_truncated && r.truncated) ? 1 : 0;
             if (ep_r) ep_r[i] = r.has_episode ? r.ep_r : 0.f;
@@ -500,6 +501,13 @@ void oracle_vec_set_reset_tape(void* p, const float* tape, int64_t episodes) {
     }
 }
 void oracle_vec_reset(void* p, float* obs, double* obs64) { ((OracleVec*)p)->v.reset(obs, obs64); }
+void oracle_vec_set_auto_reset(void* p, int on) { ((OracleVec*)p)->v.auto_reset = on != 0; }
+// SyncVecEnv::reset(int index) (sync_env.h:128-139): env `index` alone is reset; its observation row is returned.
+void oracle_vec_reset_index(void* p, int64_t index, float* obs_row, double* obs64_row) {
+    VecEnv& v = ((OracleVec*)p)->v;
+    double o[8]; v.envs[index]->reset(o);
+    for (int f = 0; f < v.F; f++) { obs_row[f] = (float)o[f]; if (obs64_row) obs64_row[f] = o[f]; }
+}
 void oracle_vec_step(void* p, const int32_t* act, float* obs, double* obs64, float* rew, float* done, uint8_t* trunc,
                      float* ep_r, float* ep_l) {
     ((OracleVec*)p)->v.step(act, obs, obs64, rew, done, trunc, ep_r, ep_l);

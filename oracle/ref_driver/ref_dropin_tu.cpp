@@ -9,8 +9,10 @@
 #include "wrappers/vec_env/base.h"
 #include "wrappers/vec_env/vec_env_wrapper.h"
 #include "wrappers/monitor.h"
+#include "wrappers/time_limit.h"
 
 #include "gym/hip_vec_env.h"
+#include "gym/hip_env.h"
 
 #include <cstdio>
 #include <type_traits>
@@ -18,6 +20,10 @@
 static_assert(std::is_base_of_v<gym::VecEnv<false>, gym::HipVecEnv>, "HipVecEnv derives from the reference's VecEnv<false>");
 static_assert(std::is_same_v<gym::VecEnv<false>::StepT, gym::VecEnvStepReturn<torch::Tensor>>, "reference step type");
 static_assert(!std::is_abstract_v<gym::HipVecEnv>, "every pure virtual of base.h:52-71 is overridden");
+
+// the single-env face under the reference's own per-env wrapper templates (common/wrapper.h:85-151, time_limit.h:13-45)
+static_assert(std::is_base_of_v<gym::Env<std::vector<double>, int>, gym::HipCartPoleEnv>, "same Env instantiation as CartPoleEnv (cartpole.h:14)");
+using WrappedSingle = gym::Monitor<gym::TimeLimit<gym::HipCartPoleEnv>, true>;
 
 // a wrapper written against the reference's VecEnvWrapper, as its own VecNormalize / VecFrameStack are (vec_env_wrapper.h:12-55)
 struct CountingWrapper : gym::VecEnvWrapper<false> {
@@ -37,6 +43,8 @@ int main(int argc, char** argv) {
     std::printf("dropin nEnvs=%d obs_size=%lld obs_type=%d ranges=%zu act_n=%lld act_size=%lld seeds=%zu first_seed=%zu is_wrapper=%d\n", w.nEnvs(),
                 (long long)w.observationSpace()->size()[0], (int)w.observationSpace()->type(), box ? box->getRange().size() : 0, act ? (long long)act->n : -1,
                 (long long)w.actionSpace()->size()[0], seeds.size(), seeds.empty() ? 0 : seeds[0], (int)w.isWrapper());
+    auto single = std::make_unique<WrappedSingle>(gym::TimeLimit<gym::HipCartPoleEnv>::make(std::make_unique<gym::HipCartPoleEnv>(), 500));
+    std::printf("single obs_size=%lld act_n=%lld\n", (long long)single->observationSpace()->size()[0], (long long)single->actionSpace()->as<gym::Discrete>()->n);
     if (argc > 1 && std::string(argv[1]) == "run") {   // only meaningful where a GPU is visible
         gym::VecEnv<false>& v = w;   // trainers hold the base type; VecEnvWrapper's step(int, Tensor) hides step(actions) by name (vec_env_wrapper.h:49)
         auto obs = v.reset();

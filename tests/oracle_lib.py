@@ -53,6 +53,8 @@ class Oracle:
         l.oracle_vec_seed.argtypes = [_vp, _u64]
         l.oracle_vec_set_reset_tape.argtypes = [_vp, _vp, _i64]
         l.oracle_vec_reset.argtypes = [_vp, _vp, _vp]
+        l.oracle_vec_set_auto_reset.argtypes = [_vp, C.c_int]
+        l.oracle_vec_reset_index.argtypes = [_vp, _i64, _vp, _vp]
         l.oracle_vec_step.argtypes = [_vp] + [_vp] * 8
         l.oracle_vec_rollout.restype = C.c_double
         l.oracle_vec_rollout.argtypes = [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]
@@ -215,6 +217,14 @@ class OracleVec:
         o64 = np.empty((self.n, self.F), np.float64) if want64 else None
         self.lib.oracle_vec_reset(self.h, _p(obs), _p(o64))
         return (obs, o64) if want64 else obs
+
+    def set_auto_reset(self, on):
+        self.lib.oracle_vec_set_auto_reset(self.h, int(on))
+
+    def reset_index(self, index):
+        row, row64 = np.empty(self.F, np.float32), np.empty(self.F, np.float64)
+        self.lib.oracle_vec_reset_index(self.h, index, _p(row), _p(row64))
+        return row, row64
 
     def step(self, actions, want64=False):
         a = np.ascontiguousarray(actions, np.int32)

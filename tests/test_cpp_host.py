@@ -179,3 +179,43 @@ def test_cpp_step_latency_demo_runs_clean():
     assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
     f = r.stdout.strip().split()
     assert f[0] == "step_latency" and int(f[-1]) == 0 and 0.5 < float(f[6]) < 200.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,seed", [("cartpole", 5), ("cartpole", -1), ("mountaincar", 3)])
+def test_single_env_face_matches_the_oracle_env_bit_for_bit(oracle, env, seed):
+    """gym::HipCartPoleEnv / HipMountainCarEnv : gym::Env<vector<double>, int> (gym/hip_env.h) driven like
+    test/classic_control.cpp:57-63 — reset, step, reset on done — against ONE oracle env without auto-reset: every double of
+    every CartPole observation identical (MountainCar: <= 1e-14), rewards and dones identical, terminal observations returned
+    (not replaced)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "hip_env_demo")
+    assert os.path.exists(exe), "build tests/cpp first"
+    cart = env == "cartpole"
+    steps, n_act = (400, 2) if cart else (1300, 3)
+    r = subprocess.run([exe, env, str(seed), str(steps)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.returncode, r.stdout[-300:], r.stderr[-1500:])
+    lines = [l.split() for l in r.stdout.strip().splitlines()]
+    v = oracle.vec(CARTPOLE if cart else MOUNTAINCAR, 1, 0, 0, threads=1)
+    if seed >= 0:
+        v.seed(seed)                                   # never seeded (-1): the default-constructed mt19937 (env.h:83)
+    v.set_auto_reset(False)
+    _, o64 = v.reset(want64=True)
+    k = 0
+    assert lines[k][0] == "reset" and [float(x) for x in lines[k][1:]] == list(o64[0]); k += 1
+    episodes = 0
+    for t in range(steps):
+        a = ((t * 2654435761 & 0xFFFFFFFF) >> 7) % n_act
+        o = v.step(np.array([a], np.int32), want64=True)
+        tag, tt, aa, rew, done, *obs = lines[k]; k += 1
+        assert tag == "step" and int(tt) == t and int(aa) == a
+        assert float(rew) == o["reward"][0] and int(done) == int(o["done"][0]), t
+        if cart:
+            assert [float(x) for x in obs] == list(o["obs64"][0]), t        # %.17g round-trips a double exactly
+        else:   # MountainCar uses the double cos(3 pos) unrounded: the device library's and glibc's differ in the last bit now and then
+            assert np.abs(np.array([float(x) for x in obs]) - o["obs64"][0]).max() <= 1e-14, t
+        if o["done"][0]:
+            episodes += 1
+            _, r64 = v.reset_index(0)
+            assert lines[k][0] == "reset" and [float(x) for x in lines[k][1:]] == list(r64); k += 1
+    assert lines[k] == ["episodes", str(episodes)] and episodes >= (5 if cart else 0)
+    assert "already returned done = True" in r.stderr or episodes < 2     # the misuse path printed the reference's warning

@@ -277,3 +277,57 @@ def test_step_info_must_be_read_before_the_next_step():
     assert len(kept.done_indices()) == 64 and kept[0]["episode"]["l"] == 5.0 and kept[0]["TimeLimit.truncated"] in (True, False)
     env.step(a)
     assert kept[0]["episode"]["l"] == 5.0             # materialised records survive later steps
+
+
+@pytest.mark.parametrize("kind", ["cartpole", "mountaincar"])
+def test_auto_reset_off_returns_terminal_observations_and_waits_for_reset_index(oracle, kind):
+    """SyncVecEnv(envs, auto_reset = false) (sync_env.h:28,44,92): a finished env is not reset — the step returns its TERMINAL
+    observation — and it is reset alone by reset(index) (sync_env.h:128-139).  Against the oracle's SyncVecEnv with the flag off."""
+    from gym_amd.vec_env import HipVecEnv
+    cart = kind == "cartpole"
+    n, T, seed = 48, 260 if cart else 420, 9
+    env = HipVecEnv("CartPole-v1" if cart else "MountainCar-v0", n, max_episode_steps=60 if cart else 200, auto_reset=False)
+    ov = oracle.vec(CARTPOLE if cart else MOUNTAINCAR, n, F_TIME_LIMIT | F_MONITOR, 60 if cart else 200)
+    ov.set_auto_reset(False)
+    env.seed(seed); ov.seed(seed)
+    assert np.array_equal(env.reset().cpu().numpy(), ov.reset())
+    acts = splitmix_actions(6, T, n, 2 if cart else 3)
+    n_done = 0
+    for t in range(T):
+        s = env.step(torch.from_numpy(acts[t].astype(np.int32)).cuda())
+        r = ov.step(acts[t], want64=True)
+        assert np.array_equal(s.done.cpu().numpy()[:, 0], r["done"]) and np.array_equal(s.reward.cpu().numpy()[:, 0], r["reward"]), t
+        got = s.observation.cpu().numpy()
+        if cart:
+            assert np.array_equal(got, r["obs"]), t                         # terminal rows included
+            assert np.array_equal(env.engine.state_f64().cpu().numpy(), r["obs64"]), t
+        else:
+            assert np.abs(got - r["obs"]).max() <= 1e-7, t
+        for i in np.nonzero(r["done"])[0]:
+            n_done += 1
+            info = s.info[int(i)]
+            assert info["episode"]["l"] == r["ep_l"][i] and info["TimeLimit.truncated"] == bool(r["truncated"][i])
+            row = env.reset(int(i)).cpu().numpy()
+            orow, _ = ov.reset_index(int(i))
+            assert np.array_equal(row, orow), (t, i)
+    assert n_done > n and env.engine.poll_error() == 0 and env.engine.episode_stats()[0] == n_done
+
+
+def test_auto_reset_off_stepping_a_finished_env_is_reported_not_simulated():
+    """The misuse the reference's Monitor reports on stderr (monitor.h:75-77): the env stays at its terminal state, reward 0,
+    done 1, and bit 3 of the error word is set."""
+    from gym_amd.vec_env import HipVecEnv
+    env = HipVecEnv("CartPole-v1", 8, max_episode_steps=3, auto_reset=False)
+    env.seed(0)
+    env.reset()
+    a = torch.zeros(8, dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        s = env.step(a)
+    assert s.done.sum().item() == 8 and env.engine.poll_error() == 0
+    terminal = s.observation.clone()
+    s = env.step(a)
+    assert torch.equal(s.observation, terminal) and s.reward.abs().sum().item() == 0 and s.done.sum().item() == 8
+    assert env.engine.poll_error() & 8 and env.engine.episode_stats()[0] == 8      # no second episode record
+    assert env.reset(2).shape == (4,)
+    s = env.step(a)
+    assert s.done[2].item() == 0 and s.reward[2].item() == 1.0 and s.done.sum().item() == 7

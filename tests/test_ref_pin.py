@@ -214,5 +214,7 @@ def test_dropin_compiles_against_the_reference_headers_and_describes_itself():
     vec_env_wrapper.h, monitor.h and spaces, linked against libgymhip.so — that it exists means it compiled and linked."""
     r = subprocess.run([DROPIN], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-1000:]
-    f = dict(kv.split("=") for kv in r.stdout.split()[1:])
+    lines = r.stdout.strip().splitlines()
+    assert lines[1].split() == ["single", "obs_size=4", "act_n=2"]     # Monitor<TimeLimit<HipCartPoleEnv>>: the reference's own wrapper templates over the single-env face
+    f = dict(kv.split("=") for kv in lines[0].split()[1:])
     assert f == {"nEnvs": "64", "obs_size": "4", "obs_type": "6", "ranges": "4", "act_n": "2", "act_size": "2", "seeds": "64", "first_seed": "7", "is_wrapper": "0"}
