@@ -563,7 +563,7 @@ def main():
         print(f"bench.py: rank {rank} stalled in {in_flight[0]!r}", file=sys.stderr, flush=True)
         os._exit(3)
 
-    dog = threading.Timer(float(os.environ.get("GYM_BENCH_EXTRA_TIMEOUT", "300")), on_stall)
+    dog = threading.Timer(float(os.environ.get("GYM_BENCH_EXTRA_TIMEOUT", "300" if world == 1 else "150")), on_stall)
     dog.daemon = True
     dog.start()
 
