@@ -10,6 +10,7 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <cassert>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -17,10 +18,17 @@
 #include <limits>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #ifdef GYMHIP_USE_REFERENCE_HEADERS
 #include "spaces/box.h"        // the reference's own Box<T> / Discrete (its include root must be on the include path)
 #include "spaces/discrete.h"
+#include "wrappers/vec_env/updateable.h"   // Updateable / Updater
+#if __has_include("boost/algorithm/string.hpp")
+#include "wrappers/vec_env/vec_normalize.h"   // VecNormalizeStateRewardPair (that header needs boost)
+#else
+namespace gym { template <bool dict> struct VecNormalizeStateRewardPair { infer_type<dict> state; torch::Tensor reward, discounts; }; }   // vec_normalize.h:14-18
+#endif
 #else
 #include "gym/vec_env.h"
 #endif
@@ -50,7 +58,7 @@ struct HipVecEnvOptions {
     std::function<void(double* moments, size_t count, void* stream)> allreduce;
 };
 
-class HipVecEnv : public VecEnv<false> {
+class HipVecEnv : public VecEnv<false>, public Updateable<VecNormalizeStateRewardPair<false>> {
 public:
     explicit HipVecEnv(HipVecEnvOptions o) : VecEnv<false>((int)o.n_envs, makeObsSpace(o.env_kind), makeActSpace(o.env_kind)), opt(std::move(o)) {
         t_start = std::chrono::high_resolution_clock::now();
@@ -199,6 +207,9 @@ public:
         ok(gymhip_update_norm_stats(h, s.defined() ? s.data_ptr<float>() : nullptr, s.defined() ? s.size(0) : 0,
                                     r.defined() ? r.data_ptr<float>() : nullptr, r.defined() ? r.size(0) : 0, opt.stream), "gymhip_update_norm_stats");
     }
+    // the observer face a learner's Updater<VecNormalizeStateRewardPair<false>> calls (updateable.h:10-31, vec_normalize.h:191-206;
+    // `discounts` is ignored there too)
+    void update(VecNormalizeStateRewardPair<false>&& x) override { update(x.state, x.reward); }
     // The reference's per-index step is a stub that does not step: it returns the BUFFERED reward / done of env `index` as
     // [1] tensors and its buffered info map (sync_env.h:141-157; the observation line is commented out there — the buffered
     // row is returned here, as that code intended).

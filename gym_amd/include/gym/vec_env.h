@@ -232,6 +232,27 @@ protected:
     std::unique_ptr<VecEnv<dict>> venv{nullptr};
 };
 
+// updateable.h:10-31: the observer a learner uses to push rollout tensors into VecNormalize
+template <class... Args> struct Updateable {
+    virtual void update(Args&&...) = 0;
+};
+template <class... Args> struct Updater {
+    void subscribe(Updateable<Args...>* sub) {
+        if (!sub) throw std::invalid_argument("Updater::subscribe(nullptr)");   // the reference asserts
+        updateables.emplace_back(sub);
+    }
+    void notifyOne(Args&&... args) {   // only the FIRST subscriber is told (updateable.h:26-29)
+        if (!updateables.empty()) updateables[0]->update(std::forward<Args>(args)...);
+    }
+private:
+    std::vector<Updateable<Args...>*> updateables{};
+};
+
+template <bool dict> struct VecNormalizeStateRewardPair {   // vec_normalize.h:14-18
+    infer_type<dict> state;
+    torch::Tensor reward, discounts;
+};
+
 }  // namespace gym
 
 #endif  // GYMHIP_USE_REFERENCE_HEADERS

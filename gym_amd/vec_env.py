@@ -337,6 +337,22 @@ class VecEnvWrapper(VecEnv):
         return self.venv.seed(_seed)
 
 
+class Updater:
+    """updateable.h:16-31: the observer a learner holds; `subscribe` appends, `notifyOne` tells only the FIRST subscriber."""
+
+    def __init__(self):
+        self._updateables = []
+
+    def subscribe(self, sub):
+        if sub is None or not callable(getattr(sub, "update", None)):
+            raise ValueError("Updater.subscribe needs an object with update(...)")   # the reference asserts a non-null pointer
+        self._updateables.append(sub)
+
+    def notifyOne(self, *args):
+        if self._updateables:
+            self._updateables[0].update(*args)
+
+
 class VecNormalize(VecEnvWrapper):
     """gym::VecNormalize<false, isTraining, normReward, normObs> (vec_normalize.h:20-232); TrainingVecNormRO =
     VecNormalize(venv) with the defaults (gym_.h:15-16).  Must wrap a HipVecEnv before its first reset: the

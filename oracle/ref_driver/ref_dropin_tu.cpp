@@ -20,6 +20,8 @@
 static_assert(std::is_base_of_v<gym::VecEnv<false>, gym::HipVecEnv>, "HipVecEnv derives from the reference's VecEnv<false>");
 static_assert(std::is_same_v<gym::VecEnv<false>::StepT, gym::VecEnvStepReturn<torch::Tensor>>, "reference step type");
 static_assert(!std::is_abstract_v<gym::HipVecEnv>, "every pure virtual of base.h:52-71 is overridden");
+static_assert(std::is_base_of_v<gym::Updateable<gym::VecNormalizeStateRewardPair<false>>, gym::HipVecEnv>,
+              "subscribable to the reference's Updater, as VecNormalize is (updateable.h:10-31, vec_normalize.h:21)");
 
 // the single-env face under the reference's own per-env wrapper templates (common/wrapper.h:85-151, time_limit.h:13-45)
 static_assert(std::is_base_of_v<gym::Env<std::vector<double>, int>, gym::HipCartPoleEnv>, "same Env instantiation as CartPoleEnv (cartpole.h:14)");

@@ -72,7 +72,9 @@ int main(int argc, char** argv) {
         const int64_t F = cart ? 4 : 2;
         auto rows = torch::full({3, n, F}, 0.25f), rew = torch::full({3, n}, -1.0f);
         const float count_before = trained->normStats().cpu()[2 * F].item<float>();
-        trained->update(rows, rew);
+        gym::Updater<gym::VecNormalizeStateRewardPair<false>> learner;   // the observer a learner holds (updateable.h:16-31)
+        learner.subscribe(trained);
+        learner.notifyOne({rows, rew, torch::Tensor()});
         auto st = trained->normStats().cpu();
         auto row = env->reset(5);
         std::printf("update %d %d\n", (int)(st[2 * F].item<float>() == count_before + 3.0f * n), (int)(row.dim() == 1 && row.size(0) == F));

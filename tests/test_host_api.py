@@ -68,3 +68,19 @@ def test_counter_word_layout_constants_documented():
     assert int(re.search(r"GYMHIP_COUNTER_STEP_BITS_MOUNTAINCAR (\d+)", hdr).group(1)) == 30
     # a CartPole episode never exceeds 501 steps (cartpole.cpp:64) < 2^10; 20 cursor bits = 1,048,575 tape rows
     assert 501 < 1 << 10
+
+
+def test_updater_tells_only_the_first_subscriber():
+    """updateable.h:16-31: subscribe appends; notifyOne forwards its arguments to updateables[0] only, and does nothing
+    while nobody has subscribed."""
+    class Sub:
+        def __init__(self): self.got = []
+        def update(self, state, reward): self.got.append((state, reward))
+    u = V.Updater()
+    u.notifyOne("s", "r")                      # no subscriber: a no-op
+    a, b = Sub(), Sub()
+    u.subscribe(a); u.subscribe(b)
+    u.notifyOne("s0", "r0"); u.notifyOne("s1", None)
+    assert a.got == [("s0", "r0"), ("s1", None)] and b.got == []
+    with pytest.raises(ValueError):
+        u.subscribe(None)
