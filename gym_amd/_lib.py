@@ -121,6 +121,7 @@ SIGNATURES = {
     "gymhip_atari_reset_indexed": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_step_indexed": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gymhip_atari_materialize_nhwc": (C.c_int, [_vp, _vp, _vp]),
+    "gymhip_atari_materialize_nhwc_as_written": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_materialize_nchw_f32": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_materialize_nchw_16": (C.c_int, [_vp, _vp, C.c_int, _vp]),
 }

@@ -98,6 +98,19 @@ class AtariPreprocessor:
         L.check(self.lib.gymhip_atari_materialize_nhwc(self.h, C.c_void_p(out.data_ptr()), self._stream()), "gymhip_atari_materialize_nhwc")
         return out
 
+    def stacked_nhwc_as_written(self, out: torch.Tensor | None = None) -> torch.Tensor:
+        """What the reference's VecFrameStack returns AS WRITTEN over WarpFrame's channels-last space
+        (stacked_observation.h:126-130 passes stackDim where stack() expects a size): channel 0 = the previous call's
+        channel 1, channels 1.. = the newest frame.  int8 [N, 84, 84, k] — the reference's reported dtype
+        (make_shape<uint8_t> -> kChar, spaces/util.h:60-63); the bytes are the uint8 pixels."""
+        if out is None:
+            out = torch.empty((self.n, *self.dst_hw, self.k), dtype=torch.int8, device=self.device)
+        if out.dtype not in (torch.int8, torch.uint8) or not out.is_contiguous() or out.numel() != self.n * self.k * self.dst_hw[0] * self.dst_hw[1]:
+            raise ValueError("out must be a contiguous int8 / uint8 [N, H, W, k] tensor")
+        L.check(self.lib.gymhip_atari_materialize_nhwc_as_written(self.h, C.c_void_p(out.data_ptr()), self._stream()),
+                "gymhip_atari_materialize_nhwc_as_written")
+        return out
+
     def stacked_nchw_f32(self, out: torch.Tensor | None = None) -> torch.Tensor:
         """VecNormAndPermute(VecFrameStack(...)) observation: float32 [N, k, 84, 84] in [0, 1]."""
         if out is None:

@@ -273,6 +273,23 @@ __global__ __launch_bounds__(kBlock) void materialize_nhwc_kernel(const uint8_t*
     }
 }
 
+// The reference's stack AS WRITTEN (gymhip.h): channel 0 = plane `first_slot` of the ring (or zeros when first_slot < 0),
+// channels 1 .. k-1 = the newest plane.
+__global__ __launch_bounds__(kBlock) void materialize_nhwc_as_written_kernel(const uint8_t* ring, uint8_t* out, int64_t n, int P, int k, int head, int first_slot) {
+    const int64_t total = n * (int64_t)P;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < total; j += (int64_t)gridDim.x * kBlock) {
+        const int64_t e = j / P; const int px = (int)(j - e * P);
+        const uint32_t newest = ring[(e * k + head) * (int64_t)P + px];
+        const uint32_t first = first_slot < 0 ? 0u : ring[(e * k + first_slot) * (int64_t)P + px];
+        if (k == 4) {
+            ((uint32_t*)out)[j] = first | (newest << 8) | (newest << 16) | (newest << 24);
+        } else {
+            out[j * k] = (uint8_t)first;
+            for (int c = 1; c < k; c++) out[j * k + c] = (uint8_t)newest;
+        }
+    }
+}
+
 // ring -> NCHW [N][k][P] = float(u8) / 255 (vec_atari.cpp:74-76).  A write-dominated stream (1 B in, 4 or 2 B out per pixel,
 // 231-462 MB per 4096-env call, written once and far larger than the Infinity Cache), so: non-temporal loads and stores, a
 // workgroup owns one contiguous piece of one (env, channel) plane — the ring-slot arithmetic is per workgroup and scalar, no
@@ -363,6 +380,7 @@ struct gymhip_atari {
     int max_taps;
     size_t lds_bytes;
     bool did_reset;
+    int64_t updates_since_reset;   // VecFrameStack::stepWait calls since the last reset (the as-written view needs 0 / 1 / more)
     uint32_t* lut;        // INDEX8 colour table (device, 256 entries R | G<<8 | B<<16) or null until gymhip_atari_set_palette
 };
 
@@ -436,7 +454,7 @@ int gymhip_atari_create(const gymhip_atari_config* cfg, int device, gymhip_atari
     gymhip_atari* h = new (std::nothrow) gymhip_atari();
     if (!h) return fail(GYMHIP_EINVAL, "out of host memory");
     std::memset(h, 0, sizeof *h);
-    h->cfg = *cfg; h->device = device; h->head = 0; h->did_reset = false;
+    h->cfg = *cfg; h->device = device; h->head = 0; h->did_reset = false; h->updates_since_reset = 0;
     h->max_taps = std::max(xt.max_taps, yt.max_taps);
     const size_t hw = (size_t)cfg->src_h * cfg->src_w;
     h->lds_bytes = ((hw + 15) & ~(size_t)15) + (sizeof(int32_t) + sizeof(float)) * cfg->dst_h * kMaxT + 256 * sizeof(uint32_t);
@@ -513,6 +531,7 @@ static int reset_any(gymhip_atari* h, bool indexed, const uint8_t* frames, void*
     HIP_TRY(hipMemsetAsync(h->ring, 0, (size_t)h->cfg.n_envs * h->cfg.n_stack * plane, (hipStream_t)stream));   // stacked_observation.h:107
     h->head = h->cfg.n_stack - 1;
     h->did_reset = true;
+    h->updates_since_reset = 0;
     return launch_preprocess(h, indexed, frames, h->ring, plane * h->cfg.n_stack, plane * h->head, nullptr, false, (hipStream_t)stream);
 }
 
@@ -522,6 +541,7 @@ static int step_any(gymhip_atari* h, bool indexed, const uint8_t* frames, const 
     if (!h->did_reset) return fail(GYMHIP_ESTATE, "atari step before reset");
     if (indexed && !h->lut) return fail(GYMHIP_ESTATE, "indexed frames need a colour table first (gymhip_atari_set_palette)");
     const int64_t plane = (int64_t)h->cfg.dst_h * h->cfg.dst_w;
+    h->updates_since_reset++;
     h->head = (h->head + 1) % h->cfg.n_stack;   // ring advance == the reference's roll(-1) + write-last (stacked_observation.h:126-130, intended semantics)
     return launch_preprocess(h, indexed, frames, h->ring, plane * h->cfg.n_stack, plane * h->head, done, true, (hipStream_t)stream);
 }
@@ -538,6 +558,25 @@ int gymhip_atari_materialize_nhwc(gymhip_atari* h, uint8_t* out, void* stream) {
     if (!out) return fail(GYMHIP_EINVAL, "out is null");
     const int P = h->cfg.dst_h * h->cfg.dst_w;
     hipLaunchKernelGGL(materialize_nhwc_kernel, dim3(2048), dim3(kBlock), 0, (hipStream_t)stream, h->ring, out, h->cfg.n_envs, P, h->cfg.n_stack, h->head);
+    HIP_TRY(hipGetLastError());
+    return GYMHIP_OK;
+}
+
+int gymhip_atari_materialize_nhwc_as_written(gymhip_atari* h, uint8_t* out, void* stream) {
+    if (int rc = check_atari(h)) return rc;
+    if (!out) return fail(GYMHIP_EINVAL, "out is null");
+    if (h->cfg.n_stack < 2) return fail(GYMHIP_EINVAL, "the as-written view needs n_stack >= 2 (with one channel the reference's stack never changes after reset)");
+    if (h->cfg.clear_on_done) return fail(GYMHIP_EINVAL, "the as-written view needs clear_on_done = 0 (the reference never clears the stack)");
+    if (!h->did_reset) return fail(GYMHIP_ESTATE, "gymhip_atari_materialize_nhwc_as_written before gymhip_atari_reset");
+    const int P = h->cfg.dst_h * h->cfg.dst_w, k = h->cfg.n_stack;
+    if (h->updates_since_reset == 0) {   // straight after reset: [0, .., 0, f], the same as the intended view
+        hipLaunchKernelGGL(materialize_nhwc_kernel, dim3(2048), dim3(kBlock), 0, (hipStream_t)stream, h->ring, out, h->cfg.n_envs, P, k, h->head);
+    } else {
+        // channel 0 = the previous call's channel 1: the previous frame, except on the first update after a reset with k >= 3,
+        // where the reset stack's channel 1 is still zero
+        const int first_slot = (h->updates_since_reset == 1 && k >= 3) ? -1 : (h->head + k - 1) % k;
+        hipLaunchKernelGGL(materialize_nhwc_as_written_kernel, dim3(2048), dim3(kBlock), 0, (hipStream_t)stream, h->ring, out, h->cfg.n_envs, P, k, h->head, first_slot);
+    }
     HIP_TRY(hipGetLastError());
     return GYMHIP_OK;
 }

@@ -619,6 +619,20 @@ void oracle_framestack_update(uint8_t* stack, const uint8_t* frame, int64_t n, i
         s[k - 1] = frame[(size_t)e * hw + p];
     }
 }
+// The reference AS WRITTEN for a channels-last stack (stacked_observation.h:126-130 + 96-99): update() rolls the stack by -C
+// along the last dim (:128), then calls stack(y, x, stackDim, ...) — passing stackDim = -1 where stack() expects a SIZE — so the
+// write is y.index_put_({"...", Slice(-(-1))}, x), i.e. y[..., 1:] = x broadcast over the k-1 trailing channels.  Feeding
+// frames 1,2,3,4 after a reset gives [3,4,4,4].  Restated literally: a left roll by one (channel 0 wraps to the end), then
+// every channel >= 1 takes the new frame.  (k = 1: the slice is empty, the stack never changes after reset.)
+void oracle_framestack_update_as_written(uint8_t* stack, const uint8_t* frame, int64_t n, int hw, int k) {
+    for (int64_t e = 0; e < n; e++) for (int p = 0; p < hw; p++) {
+        uint8_t* s = stack + ((size_t)e * hw + p) * k;
+        const uint8_t first = s[0];
+        for (int c = 0; c + 1 < k; c++) s[c] = s[c + 1];      // torch::roll(y, -1, -1)
+        s[k - 1] = first;
+        for (int c = 1; c < k; c++) s[c] = frame[(size_t)e * hw + p];   // y[..., 1:] = x
+    }
+}
 // VecNormAndPermute::observation — wrappers/vec_env/vec_atari.cpp:70-81: NHWC -> NCHW, / 255 -> float32.
 void oracle_norm_permute(const uint8_t* nhwc, int64_t n, int hw, int k, float* nchw) {
     for (int64_t e = 0; e < n; e++) for (int c = 0; c < k; c++) for (int p = 0; p < hw; p++)

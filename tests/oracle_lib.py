@@ -76,6 +76,7 @@ class Oracle:
         l.oracle_area_table.argtypes = [C.c_int, C.c_int, _vp, _vp, _vp, C.c_int]
         l.oracle_framestack_reset.argtypes = [_vp, _vp, _i64, C.c_int, C.c_int]
         l.oracle_framestack_update.argtypes = [_vp, _vp, _i64, C.c_int, C.c_int]
+        l.oracle_framestack_update_as_written.argtypes = [_vp, _vp, _i64, C.c_int, C.c_int]
         l.oracle_norm_permute.argtypes = [_vp, _i64, C.c_int, C.c_int, _vp]
 
     # ---- RNG ------------------------------------------------------------------------------------------
@@ -163,6 +164,11 @@ class Oracle:
     def framestack_update(self, stack, frame):
         n, hw, k = stack.shape[0], frame[0].size, stack.shape[-1]
         self.lib.oracle_framestack_update(_p(stack), _p(np.ascontiguousarray(frame)), n, hw, k)
+
+    def framestack_update_as_written(self, stack, frame):
+        """stacked_observation.h:126-130 as written (channels-last): roll by -1, then channels 1.. take the new frame."""
+        n, hw, k = stack.shape[0], frame[0].size, stack.shape[-1]
+        self.lib.oracle_framestack_update_as_written(_p(stack), _p(np.ascontiguousarray(frame)), n, hw, k)
 
     def atari_chain(self, n, seed, game_base, palette, frame_skip=4, noop_max=30, life_loss=True, fire=False, clip=True):
         """The reference's Atari wrapper chain (AtariWrapper::make) over the scripted emulator, n envs, SyncVecEnv auto-reset."""

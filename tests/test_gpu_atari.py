@@ -139,6 +139,36 @@ def test_frame_stack_other_depths(oracle, k):
         assert np.array_equal(pp.stacked_nchw_f32().cpu().numpy(), oracle.norm_permute(stack))
 
 
+@pytest.mark.parametrize("k", [2, 3, 4, 8])
+def test_frame_stack_as_written_view(oracle, k):
+    """gymhip_atari_materialize_nhwc_as_written: the reference's VecFrameStack output as written (channel 0 = the previous
+    call's channel 1, channels 1.. = the newest frame; int8), against the oracle's literal restatement — which
+    tests/test_oracle_atari.py pins to the torch calls themselves.  A second reset() starts over; the intended view of the
+    same ring is unaffected."""
+    from gym_amd.atari import AtariPreprocessor
+    n = 3
+    pp = AtariPreprocessor(n, n_stack=k)
+    for round_ in range(2):
+        stack = np.zeros((n, 84, 84, k), np.uint8)
+        intended = np.zeros((n, 84, 84, k), np.uint8)
+        f0 = counter_frames(5 + round_, n, 0)
+        pp.reset(torch.from_numpy(f0).cuda())
+        oracle.framestack_reset(stack, oracle.atari_preprocess(f0))
+        oracle.framestack_reset(intended, oracle.atari_preprocess(f0))
+        got = pp.stacked_nhwc_as_written()
+        assert got.dtype == torch.int8 and np.array_equal(got.view(torch.uint8).cpu().numpy(), stack)
+        for t in range(1, k + 4):
+            f = counter_frames(5 + round_, n, t)
+            pp.step(torch.from_numpy(f).cuda())
+            g = oracle.atari_preprocess(f)
+            oracle.framestack_update_as_written(stack, g)
+            oracle.framestack_update(intended, g)
+            assert np.array_equal(pp.stacked_nhwc_as_written().view(torch.uint8).cpu().numpy(), stack), (round_, t)
+            assert np.array_equal(pp.stacked_nhwc().cpu().numpy(), intended), (round_, t)
+    with pytest.raises(Exception):
+        AtariPreprocessor(n, n_stack=1).stacked_nhwc_as_written()
+
+
 def test_clear_on_done_option():
     """clear_on_done=1 (SB3 semantics; the reference never clears): finished envs see zeros in the older channels."""
     from gym_amd.atari import AtariPreprocessor

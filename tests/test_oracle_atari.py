@@ -5,6 +5,7 @@ cv::cvtColor / cv::resize themselves is UNPINNED; what is pinned here is the pub
 BT.601 fixed-point gray, computeResizeAreaTab's per-axis tables, and area averaging against an independent float64
 box-integration written below (+-1 LSB)."""
 import numpy as np
+import pytest
 
 from tests.test_gpu_atari import counter_frames, structured_frames
 
@@ -80,7 +81,7 @@ def test_preprocess_is_max_then_gray_then_resize(oracle):
 
 def test_frame_stack_intended_semantics(oracle):
     """Intended (SB3) semantics: reset -> [0,0,0,f1]; updates shift left.  The reference as written yields [3,4,4,4]
-    after frames 1..4 — documented divergence, not reproduced."""
+    after frames 1..4 — a documented divergence; the as-written form is a separate view (next test)."""
     n, hw, k = 2, 6, 4
     stack = np.zeros((n, hw, k), np.uint8)
     f = lambda v: np.full((n, hw), v, np.uint8)
@@ -94,3 +95,36 @@ def test_frame_stack_intended_semantics(oracle):
     nchw = oracle.norm_permute(stack.reshape(n, 2, 3, k))
     assert nchw.shape == (n, k, 2, 3) and nchw.dtype == np.float32
     assert np.array_equal(nchw[0, :, 1, 2], (np.array([2, 3, 4, 5], np.float32) / np.float32(255)))
+
+
+@pytest.mark.parametrize("k", [2, 3, 4, 8])
+def test_frame_stack_as_written_equals_the_literal_torch_calls(oracle, k):
+    """The reference's StackedObservation over a channels-last space IS four torch calls (stacked_observation.h:96-99,
+    106-109, 126-130); its header cannot be compiled here (common/utils.h needs OpenCV), so the as-written restatement is
+    pinned against those calls issued literally through torch's CPU ops, on the int8 (kChar) buffer the reference
+    allocates (spaces/util.h:60-63, stacked_observation.h:208): reset -> zero, y[..., -C:] = x; update -> roll(y, -C, -1),
+    then stack(y, x, stackDim = -1) = y[..., -(-1):] = x.  Frames 1,2,3,4 -> [3,4,4,4]."""
+    import torch
+    n, H, W = 3, 5, 4
+    rng = np.random.default_rng(k)
+    frames = rng.integers(0, 256, (7, n, H, W, 1), dtype=np.uint8)
+    y = torch.zeros((n, H, W, k), dtype=torch.int8)
+    x0 = torch.from_numpy(frames[0]).view(torch.int8)
+    y[...] = 0
+    y[..., -x0.size(-1):] = x0                                   # reset: stack(y, x, x.size(stackDim), false)
+    stack = np.zeros((n, H * W, k), np.uint8)
+    oracle.framestack_reset(stack, frames[0].reshape(n, H * W))
+    assert np.array_equal(y.view(torch.uint8).numpy().reshape(n, H * W, k), stack)
+    stack_dim = -1
+    for t in range(1, 7):
+        x = torch.from_numpy(frames[t]).view(torch.int8)
+        y = torch.roll(y, -x.size(stack_dim), stack_dim)          # :127-128
+        y[..., -stack_dim:] = x                                   # :129 -> stack(y, x, size = stackDim, false): Slice(-size)
+        oracle.framestack_update_as_written(stack, frames[t].reshape(n, H * W))
+        assert np.array_equal(y.view(torch.uint8).numpy().reshape(n, H * W, k), stack), t
+    if k == 4:
+        s = np.zeros((1, 1, 4), np.uint8)
+        oracle.framestack_reset(s, np.full((1, 1), 1, np.uint8))
+        for v in (2, 3, 4):
+            oracle.framestack_update_as_written(s, np.full((1, 1), v, np.uint8))
+        assert (s[0, 0] == [3, 4, 4, 4]).all()
