@@ -53,6 +53,10 @@ struct AtariFrontEndOptions {
     bool terminal_on_life_loss = true;  // EpisodicLifeEnv in the chain (atari_wrappers.cpp:103-109)
     bool fire_reset = false;            // the game's action set has FIRE (atari_wrappers.cpp:111-113)
     bool clip_reward = true;            // atari_wrappers.cpp:117-119
+    bool max_as_written = false;        // false = max of the last two frames (the intended semantics, python_gym/atari_wrappers.py:139-150).
+                                        // true  = the reference as it runs today: AtariEnv::getObs returns its one cv::Mat by value
+                                        // (atari_env.cpp:11-17), a header copy, so both MaxAndSkip buffers alias the same pixels and
+                                        // cv::max (atari_wrappers.cpp:30) yields the LAST emulated frame.
     int n_stack = 4;                    // VecFrameStack
     int src_h = 210, src_w = 160, dst_h = 84, dst_w = 84;
     int device = 0;
@@ -149,7 +153,11 @@ private:
     uint8_t* slot(int64_t i, int k) { return staging + ((size_t)i * 2 + k) * hw; }
     // the observation handed upwards is materialised at the moment the reference would compute it
     void emit_single(int64_t i) { std::memcpy(slot(i, 0), envs[i].emu->screen(), hw); std::memcpy(slot(i, 1), envs[i].emu->screen(), hw); }
-    void emit_max(int64_t i) { std::memcpy(slot(i, 0), envs[i].buf0.data(), hw); std::memcpy(slot(i, 1), envs[i].buf1.data(), hw); }
+    void emit_max(int64_t i) {
+        if (opt.max_as_written) { emit_single(i); return; }   // every call site follows the group's last act(): the screen IS that frame
+        emit_max_of_two(i);
+    }
+    void emit_max_of_two(int64_t i) { std::memcpy(slot(i, 0), envs[i].buf0.data(), hw); std::memcpy(slot(i, 1), envs[i].buf1.data(), hw); }
 
     // AtariEnv::step with frameSkip 1 (atari_env.cpp:101-113)
     StepOut base_step(EnvState& s, int action) {

@@ -702,6 +702,11 @@ struct NoopResetEnv : Env {   // noop_reset.h:43-58
 };
 struct MaxAndSkipEnv : Env {   // atari_wrappers.cpp:10-33
     Env* in; int skip; Frame buf[2];
+    // AS WRITTEN (optional): AtariEnv::getObs returns `data` BY VALUE (atari_env.cpp:11-17) and a cv::Mat copy is a header
+    // onto the same pixels, so m_ObsBuffer[0], m_ObsBuffer[1] and every later getObs result alias AtariEnv's one frame
+    // buffer: when cv::max runs (atari_wrappers.cpp:30) both operands hold the pixels of the LAST getObs call.  The frames
+    // here are value copies (the intended semantics); the aliased result is restated by re-reading the base env's screen.
+    const BaseEnv* aliased = nullptr;
     MaxAndSkipEnv(Env* e, int s, const Frame& blank) : in(e), skip(s) { buf[0] = blank; buf[1] = blank; }
     Frame reset() override { return in->reset(); }
     Resp step(int a) override {
@@ -713,6 +718,7 @@ struct MaxAndSkipEnv : Env {   // atari_wrappers.cpp:10-33
             if (resp.done) break;
             t++;
         }
+        if (aliased) { resp.obs = aliased->colour(); resp.reward = total; return resp; }   // max(x, x) of the one shared buffer
         resp.obs.resize(buf[0].size());
         for (size_t k = 0; k < buf[0].size(); k++) resp.obs[k] = std::max(buf[0][k], buf[1][k]);   // cv::max
         resp.reward = total;
@@ -783,6 +789,7 @@ struct ClipRewardEnv : Env {   // clip_reward.h:22-24
 struct Chain {
     std::vector<std::unique_ptr<Env>> owned;
     Env* top = nullptr;
+    BaseEnv* base = nullptr; MaxAndSkipEnv* maxskip = nullptr;
     template <class T, class... A> T* add(A&&... a) { auto p = std::make_unique<T>(std::forward<A>(a)...); T* raw = p.get(); owned.push_back(std::move(p)); return raw; }
 };
 struct VecChain { std::vector<Chain> envs; std::vector<uint32_t> palette; };
@@ -802,7 +809,9 @@ void* oracle_atari_chain_create(int64_t n, uint64_t seed, uint64_t game_base, in
         Frame blank((size_t)FakeEmulator::H * FakeEmulator::W * 3);
         for (size_t p = 0; p < blank.size() / 3; p++) { const uint32_t z = v->palette[0]; blank[3 * p] = (z >> 16) & 0xff; blank[3 * p + 1] = (z >> 8) & 0xff; blank[3 * p + 2] = z & 0xff; }
         oracle_atari::Env* e = c.add<oracle_atari::NoopResetEnv>(base, seed + (uint64_t)i, noop_max);
-        e = c.add<oracle_atari::MaxAndSkipEnv>(e, frame_skip, blank);
+        c.base = base;
+        c.maxskip = c.add<oracle_atari::MaxAndSkipEnv>(e, frame_skip, blank);
+        e = c.maxskip;
         e = c.add<oracle_atari::MonitorEnv>(e);
         if (life_loss) e = c.add<oracle_atari::EpisodicLifeEnv>(e, base);
         if (fire) e = c.add<oracle_atari::FireResetEnv>(e);
@@ -813,6 +822,8 @@ void* oracle_atari_chain_create(int64_t n, uint64_t seed, uint64_t game_base, in
     return v;
 }
 void oracle_atari_chain_destroy(void* h) { delete (oracle_atari::VecChain*)h; }
+// 1 = MaxAndSkipEnv as written (its two buffers alias AtariEnv's frame buffer: the observation is the last emulated frame)
+void oracle_atari_chain_set_max_as_written(void* h, int on) { for (auto& c : ((oracle_atari::VecChain*)h)->envs) c.maxskip->aliased = on ? c.base : nullptr; }
 // SyncVecEnv::reset (sync_env.h:66-72): frames84 u8 [n][84*84]
 void oracle_atari_chain_reset(void* h, uint8_t* frames84) {
     auto* v = (oracle_atari::VecChain*)h;

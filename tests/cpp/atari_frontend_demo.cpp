@@ -1,7 +1,7 @@
 // Drives gym::AtariFrontEnd<FakeEmulator> (gym_amd/include/gym/atari_frontend.h) like a rollout worker: reset, then T steps
 // with a fixed action stream, and dumps everything the wrapper chain returns so tests/test_cpp_host.py can compare it with
 // the oracle's class-by-class restatement of the reference chain.
-//   usage: atari_frontend_demo <n_envs> <steps> <seed> <terminal_on_life_loss 0|1> <fire_reset 0|1> <out.bin>
+//   usage: atari_frontend_demo <n_envs> <steps> <seed> <terminal_on_life_loss 0|1> <fire_reset 0|1> <out.bin> [max_as_written 0|1]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,13 +12,14 @@
 static void put(FILE* f, const void* p, size_t bytes) { if (fwrite(p, 1, bytes, f) != bytes) { std::perror("fwrite"); std::exit(9); } }
 
 int main(int argc, char** argv) {
-    if (argc != 7) { std::fprintf(stderr, "usage: %s n_envs steps seed life_loss fire out.bin\n", argv[0]); return 2; }
+    if (argc != 7 && argc != 8) { std::fprintf(stderr, "usage: %s n_envs steps seed life_loss fire out.bin\n", argv[0]); return 2; }
     const int64_t n = std::atoll(argv[1]), T = std::atoll(argv[2]);
     gym::AtariFrontEndOptions o;
     o.seed = std::strtoull(argv[3], nullptr, 10);
     o.terminal_on_life_loss = std::atoi(argv[4]) != 0;
     o.fire_reset = std::atoi(argv[5]) != 0;
     o.threads = 4;
+    o.max_as_written = argc == 8 && std::atoi(argv[7]) != 0;
     uint32_t palette[256];
     for (int k = 0; k < 256; k++) palette[k] = (k & 1) ? 0u : (uint32_t)(FakeEmulator::mix(77 + (uint64_t)k) & 0xFFFFFFu);   // NTSC-table shape: odd entries 0
     std::vector<std::unique_ptr<FakeEmulator>> emus;

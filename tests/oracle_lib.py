@@ -45,6 +45,7 @@ class Oracle:
         l.oracle_vec_create.argtypes = [C.c_int, _i64, C.c_int, _i64, C.c_int, _vp, _vp, _i64]
         l.oracle_vec_destroy.argtypes = [_vp]
         l.oracle_atari_chain_create.restype = _vp
+        l.oracle_atari_chain_set_max_as_written.argtypes = [_vp, C.c_int]
         l.oracle_atari_chain_create.argtypes = [_i64, _u64, _u64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
         l.oracle_atari_chain_destroy.argtypes = [_vp]
         l.oracle_atari_chain_reset.argtypes = [_vp, _vp]
@@ -307,6 +308,10 @@ class AtariChain:
         if getattr(self, "h", None):
             self.lib.oracle_atari_chain_destroy(self.h)
             self.h = None
+
+    def set_max_as_written(self, on=True):
+        """MaxAndSkipEnv's buffers alias AtariEnv's one frame buffer in the reference (atari_env.cpp:11-17): observation = last frame."""
+        self.lib.oracle_atari_chain_set_max_as_written(self.h, int(on))
 
     def reset(self):
         fr = np.empty((self.n, 84, 84), np.uint8)

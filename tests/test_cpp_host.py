@@ -109,8 +109,16 @@ def test_hip_atari_vec_env_is_a_vecenv_and_matches_the_reference_chain(oracle, t
 
 
 @pytest.mark.gpu
+def test_atari_front_end_max_as_written(oracle, tmp_path):
+    """AtariFrontEndOptions::max_as_written: MaxAndSkipEnv as the reference runs today — its two buffers are cv::Mat headers
+    onto AtariEnv's one frame buffer (atari_env.cpp:11-17 returns `data` by value), so cv::max sees the last emulated frame
+    twice — against the oracle chain with the same aliasing switched on."""
+    test_atari_front_end_matches_the_reference_chain(oracle, tmp_path, True, True, as_written=True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("life_loss,fire", [(True, False), (True, True), (False, True)])
-def test_atari_front_end_matches_the_reference_chain(oracle, tmp_path, life_loss, fire, exe=None):
+def test_atari_front_end_matches_the_reference_chain(oracle, tmp_path, life_loss, fire, exe=None, as_written=False):
     """(f4) gym::AtariFrontEnd — NOOP / MaxAndSkip / Monitor / EpisodicLife / FireReset control flow on the host, pinned
     double-buffered upload of palette-index screens, colour + max + warp + frame stack + permute on the GPU — against the
     oracle's class-by-class restatement of AtariWrapper::make under SyncVecEnv auto-reset, over a scripted emulator."""
@@ -118,7 +126,8 @@ def test_atari_front_end_matches_the_reference_chain(oracle, tmp_path, life_loss
     assert os.path.exists(exe), "build tests/cpp first"
     n, T, seed = 6, 90, 4
     out = tmp_path / "fe.bin"
-    r = subprocess.run([exe, str(n), str(T), str(seed), str(int(life_loss)), str(int(fire)), str(out)], capture_output=True, text=True, timeout=240)
+    r = subprocess.run([exe, str(n), str(T), str(seed), str(int(life_loss)), str(int(fire)), str(out)] + (["1"] if as_written else []),
+                       capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stderr[-2000:])
     raw = np.fromfile(out, np.uint8)
     assert tuple(raw[:16].view(np.int64)) == (n, T)
@@ -129,6 +138,8 @@ def test_atari_front_end_matches_the_reference_chain(oracle, tmp_path, life_loss
         v = raw[pos:pos + nbytes].view(dt); pos += nbytes
         return v
     chain = oracle.atari_chain(n, seed, 1000, _fake_palette(), life_loss=life_loss, fire=fire)
+    if as_written:
+        chain.set_max_as_written()
     stack = np.zeros((n, 84, 84, 4), np.uint8)
     f0 = chain.reset()
     oracle.framestack_reset(stack, f0)
