@@ -18,6 +18,7 @@ WRAP_TIME_LIMIT, WRAP_CLIP_REWARD, WRAP_MONITOR = 1, 2, 4
 WRAP_NORM_OBS, WRAP_NORM_REWARD, WRAP_NORM_TRAINING = 8, 16, 32
 WRAP_NO_AUTO_RESET = 64
 ACT_I32, ACT_I64, ACT_U8 = 0, 1, 2
+STACK_INTENDED, STACK_AS_WRITTEN = 0, 1
 OUT_F16, OUT_BF16 = 0, 1
 NOALLOC_MAX_ROWS = 1 << 26
 
@@ -121,7 +122,7 @@ SIGNATURES = {
     "gymhip_atari_reset_indexed": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_step_indexed": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gymhip_atari_materialize_nhwc": (C.c_int, [_vp, _vp, _vp]),
-    "gymhip_atari_materialize_nhwc_as_written": (C.c_int, [_vp, _vp, _vp]),
+    "gymhip_atari_set_stack_view": (C.c_int, [_vp, C.c_int]),
     "gymhip_atari_materialize_nchw_f32": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_materialize_nchw_16": (C.c_int, [_vp, _vp, C.c_int, _vp]),
 }

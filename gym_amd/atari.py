@@ -92,24 +92,23 @@ class AtariPreprocessor:
         return head.value
 
     def stacked_nhwc(self, out: torch.Tensor | None = None) -> torch.Tensor:
-        """VecFrameStack observation: uint8 [N, 84, 84, k], oldest frame in channel 0."""
+        """VecFrameStack observation [N, 84, 84, k]: uint8, oldest frame in channel 0 — or, in the as-written view, int8 (the
+        reference's kChar buffer; same bytes) with the reference's channel contents."""
         if out is None:
-            out = torch.empty((self.n, *self.dst_hw, self.k), dtype=torch.uint8, device=self.device)
+            out = torch.empty((self.n, *self.dst_hw, self.k), dtype=torch.int8 if getattr(self, "view", "intended") == "as_written" else torch.uint8,
+                              device=self.device)
         L.check(self.lib.gymhip_atari_materialize_nhwc(self.h, C.c_void_p(out.data_ptr()), self._stream()), "gymhip_atari_materialize_nhwc")
         return out
 
-    def stacked_nhwc_as_written(self, out: torch.Tensor | None = None) -> torch.Tensor:
-        """What the reference's VecFrameStack returns AS WRITTEN over WarpFrame's channels-last space
-        (stacked_observation.h:126-130 passes stackDim where stack() expects a size): channel 0 = the previous call's
-        channel 1, channels 1.. = the newest frame.  int8 [N, 84, 84, k] — the reference's reported dtype
-        (make_shape<uint8_t> -> kChar, spaces/util.h:60-63); the bytes are the uint8 pixels."""
-        if out is None:
-            out = torch.empty((self.n, *self.dst_hw, self.k), dtype=torch.int8, device=self.device)
-        if out.dtype not in (torch.int8, torch.uint8) or not out.is_contiguous() or out.numel() != self.n * self.k * self.dst_hw[0] * self.dst_hw[1]:
-            raise ValueError("out must be a contiguous int8 / uint8 [N, H, W, k] tensor")
-        L.check(self.lib.gymhip_atari_materialize_nhwc_as_written(self.h, C.c_void_p(out.data_ptr()), self._stream()),
-                "gymhip_atari_materialize_nhwc_as_written")
-        return out
+    def set_stack_view(self, view: str):
+        """"intended" (default): the shift semantics StackedObservation means to implement.  "as_written": what the reference's
+        code computes today, bug for bug — channel 0 = the previous call's channel 1, channels 1.. = the newest frame
+        (stacked_observation.h:96-99,126-130), held in an int8 buffer (spaces/util.h:60-63) so that VecNormAndPermute's / 255
+        (vec_atari.cpp:74-76) divides signed bytes.  The ring is shared; the view can be switched at any time."""
+        if view not in ("intended", "as_written"):
+            raise ValueError("view must be 'intended' or 'as_written'")
+        L.check(self.lib.gymhip_atari_set_stack_view(self.h, L.STACK_AS_WRITTEN if view == "as_written" else L.STACK_INTENDED), "gymhip_atari_set_stack_view")
+        self.view = view
 
     def stacked_nchw_f32(self, out: torch.Tensor | None = None) -> torch.Tensor:
         """VecNormAndPermute(VecFrameStack(...)) observation: float32 [N, k, 84, 84] in [0, 1]."""

@@ -303,19 +303,29 @@ template <int BF16> __device__ inline uint32_t to16(float v) {
     if (BF16) { const uint32_t u = __float_as_uint(v); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; }   // finite, non-negative input: round to nearest even
     return (uint32_t)__half_as_ushort(__float2half_rn(v));
 }
-__device__ inline float px(uint32_t w, int b) { return (float)((w >> (8 * b)) & 255u) / 255.f; }
-template <int BF16> __device__ inline uint32_t pack16(uint32_t w, int b) { return to16<BF16>(px(w, b)) | (to16<BF16>(px(w, b + 1)) << 16); }
+// SGN reads the byte as the reference's int8 buffer does (GYMHIP_STACK_AS_WRITTEN: 200 -> -56); else as the uint8 pixel.  A template
+// argument: as a run-time flag its compare + subtract per pixel cost the default view 6 % (f32) / 14 % (bf16) of its rate.
+template <int SGN> __device__ inline float px(uint32_t w, int b) {
+    if constexpr (SGN) return (float)(int)(int8_t)((w >> (8 * b)) & 255u) / 255.f;
+    else return (float)((w >> (8 * b)) & 255u) / 255.f;
+}
+template <int BF16, int SGN> __device__ inline uint32_t pack16(uint32_t w, int b) { return to16<BF16>(px<SGN>(w, b)) | (to16<BF16>(px<SGN>(w, b + 1)) << 16); }
 
 // MODE 0: f32 out, 4 px per item.  MODE 1: 16-bit out, 8 px per item.  MODE 2: 16-bit out, 4 px per item (P % 8 != 0).
 #ifndef GYMHIP_MAT_BLOCK
+constexpr int kViewIntended = -2;   // `first` argument of the materialise kernels: the intended shift view
 #define GYMHIP_MAT_BLOCK 256
 #endif
 #ifndef GYMHIP_MAT_UNR
 #define GYMHIP_MAT_UNR 4       // items whose loads are issued before the first of them is converted and stored
 #endif
 constexpr int kMatBlock = GYMHIP_MAT_BLOCK;
-template <int MODE, int BF16>
-__global__ __launch_bounds__(kMatBlock) void materialize_nchw_kernel(const uint8_t* __restrict__ ring, void* __restrict__ out, int64_t planes, int P, int k, int head, int split) {
+template <int MODE, int BF16, int AW>
+__global__ __launch_bounds__(kMatBlock) void materialize_nchw_kernel(const uint8_t* __restrict__ ring, void* __restrict__ out, int64_t planes, int P, int k, int head, int split,
+                                                                    int first) {
+    // AW = 0: the intended shift view (`first` unused).  AW = 1: the as-written view — channel 0 = ring slot `first` (zeros if < 0),
+    // channels 1.. = the newest frame, bytes read as int8.  AW = 2: the intended channel mapping with bytes read as int8 (the
+    // as-written view straight after reset(), when the two stacks hold the same planes).
     constexpr int PX = MODE == 1 ? 8 : 4;
     constexpr int UNR = GYMHIP_MAT_UNR;
     using InV = typename std::conditional<MODE == 1, u32x2v, uint32_t>::type;
@@ -324,24 +334,26 @@ __global__ __launch_bounds__(kMatBlock) void materialize_nchw_kernel(const uint8
     for (int64_t w = blockIdx.x; w < planes * split; w += gridDim.x) {
         const int64_t plane = w / split; const int piece = (int)(w - plane * split);
         const int64_t e = plane / k; const int c = (int)(plane - e * k);
-        const InV* src = (const InV*)(ring + (e * k + ((head + 1 + c) % k)) * (int64_t)P);     // channel c = the (c+1)-th oldest frame
+        const bool zero = AW == 1 && c == 0 && first < 0;
+        const int slot = AW != 1 ? (head + 1 + c) % k : (c == 0 && first >= 0 ? first : head);   // intended: channel c = the (c+1)-th oldest frame
+        const InV* src = (const InV*)(ring + (e * k + slot) * (int64_t)P);
         const int lo = piece * per_piece, hi = min(items, lo + per_piece);
         for (int q0 = lo + (int)threadIdx.x; q0 < hi; q0 += kMatBlock * UNR) {
             InV v[UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; u++) { const int q = q0 + u * kMatBlock; if (q < hi) v[u] = __builtin_nontemporal_load(src + q); }
+            for (int u = 0; u < UNR; u++) { const int q = q0 + u * kMatBlock; if (q < hi) v[u] = zero ? InV{} : __builtin_nontemporal_load(src + q); }
 #pragma unroll
             for (int u = 0; u < UNR; u++) {
                 const int q = q0 + u * kMatBlock;
                 if (q >= hi) continue;
                 if constexpr (MODE == 0) {
-                    const f32x4v o = {px(v[u], 0), px(v[u], 1), px(v[u], 2), px(v[u], 3)};
+                    const f32x4v o = {px<(AW != 0)>(v[u], 0), px<(AW != 0)>(v[u], 1), px<(AW != 0)>(v[u], 2), px<(AW != 0)>(v[u], 3)};
                     __builtin_nontemporal_store(o, (f32x4v*)out + plane * items + q);
                 } else if constexpr (MODE == 1) {
-                    const u32x4v o = {pack16<BF16>(v[u].x, 0), pack16<BF16>(v[u].x, 2), pack16<BF16>(v[u].y, 0), pack16<BF16>(v[u].y, 2)};
+                    const u32x4v o = {pack16<BF16, (AW != 0)>(v[u].x, 0), pack16<BF16, (AW != 0)>(v[u].x, 2), pack16<BF16, (AW != 0)>(v[u].y, 0), pack16<BF16, (AW != 0)>(v[u].y, 2)};
                     __builtin_nontemporal_store(o, (u32x4v*)out + plane * items + q);
                 } else {
-                    const u32x2v o = {pack16<BF16>(v[u], 0), pack16<BF16>(v[u], 2)};
+                    const u32x2v o = {pack16<BF16, (AW != 0)>(v[u], 0), pack16<BF16, (AW != 0)>(v[u], 2)};
                     __builtin_nontemporal_store(o, (u32x2v*)out + plane * items + q);
                 }
             }
@@ -381,6 +393,7 @@ struct gymhip_atari {
     size_t lds_bytes;
     bool did_reset;
     int64_t updates_since_reset;   // VecFrameStack::stepWait calls since the last reset (the as-written view needs 0 / 1 / more)
+    int view;                      // GYMHIP_STACK_INTENDED | GYMHIP_STACK_AS_WRITTEN
     uint32_t* lut;        // INDEX8 colour table (device, 256 entries R | G<<8 | B<<16) or null until gymhip_atari_set_palette
 };
 
@@ -432,6 +445,50 @@ int launch_preprocess(gymhip_atari* h, bool indexed, const uint8_t* frames, uint
 
 }  // namespace
 
+namespace {
+// `first` for the materialise kernels.  As written: straight after reset the stack is [0, .., 0, f], the same as the intended
+// view; afterwards channel 0 = the previous call's channel 1 — the previous frame, except on the first update after a reset
+// with k >= 3, where the reset stack's channel 1 is still zero.
+int view_first(const gymhip_atari* h) {
+    if (h->view == GYMHIP_STACK_INTENDED || h->updates_since_reset == 0) return kViewIntended;
+    const int k = h->cfg.n_stack;
+    return (h->updates_since_reset == 1 && k >= 3) ? -1 : (h->head + k - 1) % k;
+}
+
+// Launch shape of the NCHW materialisation: `split` workgroups per (env, channel) plane, at most kMatMaxGrid workgroups (a
+// grid-stride loop covers the rest).  GYMHIP_MAT_SPLIT / GYMHIP_MAT_GRID override for sweeps (tools/sweep_materialize.sh).
+constexpr int kMatMaxGrid = 1 << 20;
+void materialize_shape(int64_t planes, int items, int* split, unsigned* grid) {
+    int sp = (int)((2 * (int64_t)items + 7 * kMatBlock / 2) / (7 * kMatBlock));   // default: ~3.5 items per thread (14 KB out per workgroup), best of tools/sweep_materialize.sh
+    if (const char* e = getenv("GYMHIP_MAT_SPLIT")) { const int v = atoi(e); if (v > 0) sp = v; }
+    sp = std::max(1, std::min(sp, items));
+    int64_t g = planes * sp;
+    int64_t cap = kMatMaxGrid;
+    if (const char* e = getenv("GYMHIP_MAT_GRID")) { const int v = atoi(e); if (v > 0) cap = v; }
+    *split = sp; *grid = (unsigned)std::min<int64_t>(g, cap);
+}
+
+
+// One launch of the NCHW materialisation: MODE / BF16 pick the pixel format, the handle's view picks AW.  As written, the stack
+// straight after reset() equals the intended one in channel CONTENT, but its bytes are still read as int8.
+template <int MODE, int BF16> int launch_nchw(gymhip_atari* h, void* out, int px_per_item, hipStream_t s) {
+    const int P = h->cfg.dst_h * h->cfg.dst_w, k = h->cfg.n_stack;
+    const int64_t planes = h->cfg.n_envs * k;
+    int split; unsigned grid;
+    materialize_shape(planes, P / px_per_item, &split, &grid);
+    if (h->view == GYMHIP_STACK_AS_WRITTEN) {
+        // straight after reset() the stack is [0, .., 0, f] in both views: the intended mapping, with the signed reading (AW = 2)
+        const int first = view_first(h);
+        if (first == kViewIntended) hipLaunchKernelGGL((materialize_nchw_kernel<MODE, BF16, 2>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, h->head, split, 0);
+        else hipLaunchKernelGGL((materialize_nchw_kernel<MODE, BF16, 1>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, h->head, split, first);
+    } else {
+        hipLaunchKernelGGL((materialize_nchw_kernel<MODE, BF16, 0>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, h->head, split, 0);
+    }
+    HIP_TRY(hipGetLastError());
+    return GYMHIP_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int gymhip_atari_create(const gymhip_atari_config* cfg, int device, gymhip_atari** out) {
@@ -454,7 +511,7 @@ int gymhip_atari_create(const gymhip_atari_config* cfg, int device, gymhip_atari
     gymhip_atari* h = new (std::nothrow) gymhip_atari();
     if (!h) return fail(GYMHIP_EINVAL, "out of host memory");
     std::memset(h, 0, sizeof *h);
-    h->cfg = *cfg; h->device = device; h->head = 0; h->did_reset = false; h->updates_since_reset = 0;
+    h->cfg = *cfg; h->device = device; h->head = 0; h->did_reset = false; h->updates_since_reset = 0; h->view = GYMHIP_STACK_INTENDED;
     h->max_taps = std::max(xt.max_taps, yt.max_taps);
     const size_t hw = (size_t)cfg->src_h * cfg->src_w;
     h->lds_bytes = ((hw + 15) & ~(size_t)15) + (sizeof(int32_t) + sizeof(float)) * cfg->dst_h * kMaxT + 256 * sizeof(uint32_t);
@@ -553,78 +610,41 @@ int gymhip_atari_preprocess_indexed(gymhip_atari* h, const uint8_t* screens, uin
 int gymhip_atari_reset_indexed(gymhip_atari* h, const uint8_t* screens, void* stream) { return reset_any(h, true, screens, stream); }
 int gymhip_atari_step_indexed(gymhip_atari* h, const uint8_t* screens, const uint8_t* done, void* stream) { return step_any(h, true, screens, done, stream); }
 
+int gymhip_atari_set_stack_view(gymhip_atari* h, int view) {
+    if (int rc = check_atari(h)) return rc;
+    if (view != GYMHIP_STACK_INTENDED && view != GYMHIP_STACK_AS_WRITTEN) return fail(GYMHIP_EINVAL, "view must be GYMHIP_STACK_INTENDED or GYMHIP_STACK_AS_WRITTEN");
+    if (view == GYMHIP_STACK_AS_WRITTEN) {
+        if (h->cfg.n_stack < 2) return fail(GYMHIP_EINVAL, "the as-written view needs n_stack >= 2 (with one channel the reference's stack never changes after reset)");
+        if (h->cfg.clear_on_done) return fail(GYMHIP_EINVAL, "the as-written view needs clear_on_done = 0 (the reference never clears the stack)");
+    }
+    h->view = view;
+    return GYMHIP_OK;
+}
+
 int gymhip_atari_materialize_nhwc(gymhip_atari* h, uint8_t* out, void* stream) {
     if (int rc = check_atari(h)) return rc;
     if (!out) return fail(GYMHIP_EINVAL, "out is null");
-    const int P = h->cfg.dst_h * h->cfg.dst_w;
-    hipLaunchKernelGGL(materialize_nhwc_kernel, dim3(2048), dim3(kBlock), 0, (hipStream_t)stream, h->ring, out, h->cfg.n_envs, P, h->cfg.n_stack, h->head);
-    HIP_TRY(hipGetLastError());
-    return GYMHIP_OK;
-}
-
-int gymhip_atari_materialize_nhwc_as_written(gymhip_atari* h, uint8_t* out, void* stream) {
-    if (int rc = check_atari(h)) return rc;
-    if (!out) return fail(GYMHIP_EINVAL, "out is null");
-    if (h->cfg.n_stack < 2) return fail(GYMHIP_EINVAL, "the as-written view needs n_stack >= 2 (with one channel the reference's stack never changes after reset)");
-    if (h->cfg.clear_on_done) return fail(GYMHIP_EINVAL, "the as-written view needs clear_on_done = 0 (the reference never clears the stack)");
-    if (!h->did_reset) return fail(GYMHIP_ESTATE, "gymhip_atari_materialize_nhwc_as_written before gymhip_atari_reset");
     const int P = h->cfg.dst_h * h->cfg.dst_w, k = h->cfg.n_stack;
-    if (h->updates_since_reset == 0) {   // straight after reset: [0, .., 0, f], the same as the intended view
-        hipLaunchKernelGGL(materialize_nhwc_kernel, dim3(2048), dim3(kBlock), 0, (hipStream_t)stream, h->ring, out, h->cfg.n_envs, P, k, h->head);
-    } else {
-        // channel 0 = the previous call's channel 1: the previous frame, except on the first update after a reset with k >= 3,
-        // where the reset stack's channel 1 is still zero
-        const int first_slot = (h->updates_since_reset == 1 && k >= 3) ? -1 : (h->head + k - 1) % k;
-        hipLaunchKernelGGL(materialize_nhwc_as_written_kernel, dim3(2048), dim3(kBlock), 0, (hipStream_t)stream, h->ring, out, h->cfg.n_envs, P, k, h->head, first_slot);
-    }
+    const int first = view_first(h);
+    if (first == kViewIntended) hipLaunchKernelGGL(materialize_nhwc_kernel, dim3(2048), dim3(kBlock), 0, (hipStream_t)stream, h->ring, out, h->cfg.n_envs, P, k, h->head);
+    else hipLaunchKernelGGL(materialize_nhwc_as_written_kernel, dim3(2048), dim3(kBlock), 0, (hipStream_t)stream, h->ring, out, h->cfg.n_envs, P, k, h->head, first);
     HIP_TRY(hipGetLastError());
     return GYMHIP_OK;
-}
-
-// Launch shape of the NCHW materialisation: `split` workgroups per (env, channel) plane, at most kMatMaxGrid workgroups (a
-// grid-stride loop covers the rest).  GYMHIP_MAT_SPLIT / GYMHIP_MAT_GRID override for sweeps (tools/sweep_materialize.sh).
-constexpr int kMatMaxGrid = 1 << 20;
-static void materialize_shape(int64_t planes, int items, int* split, unsigned* grid) {
-    int sp = (int)((2 * (int64_t)items + 7 * kMatBlock / 2) / (7 * kMatBlock));   // default: ~3.5 items per thread (14 KB out per workgroup), best of tools/sweep_materialize.sh
-    if (const char* e = getenv("GYMHIP_MAT_SPLIT")) { const int v = atoi(e); if (v > 0) sp = v; }
-    sp = std::max(1, std::min(sp, items));
-    int64_t g = planes * sp;
-    int64_t cap = kMatMaxGrid;
-    if (const char* e = getenv("GYMHIP_MAT_GRID")) { const int v = atoi(e); if (v > 0) cap = v; }
-    *split = sp; *grid = (unsigned)std::min<int64_t>(g, cap);
 }
 
 int gymhip_atari_materialize_nchw_f32(gymhip_atari* h, float* out, void* stream) {
     if (int rc = check_atari(h)) return rc;
     if (!out) return fail(GYMHIP_EINVAL, "out is null");
-    const int P = h->cfg.dst_h * h->cfg.dst_w;       // dst_w % 4 == 0 (gymhip_atari_create) => P % 4 == 0
-    const int64_t planes = h->cfg.n_envs * h->cfg.n_stack;
-    int split; unsigned grid;
-    materialize_shape(planes, P / 4, &split, &grid);
-    hipLaunchKernelGGL((materialize_nchw_kernel<0, 0>), dim3(grid), dim3(kMatBlock), 0, (hipStream_t)stream, h->ring, (void*)out, planes, P, h->cfg.n_stack, h->head, split);
-    HIP_TRY(hipGetLastError());
-    return GYMHIP_OK;
+    return launch_nchw<0, 0>(h, out, 4, (hipStream_t)stream);       // dst_w % 4 == 0 (gymhip_atari_create) => P % 4 == 0
 }
-
 int gymhip_atari_materialize_nchw_16(gymhip_atari* h, void* out, int dtype, void* stream) {
     if (int rc = check_atari(h)) return rc;
     if (!out) return fail(GYMHIP_EINVAL, "out is null");
     if (dtype != GYMHIP_OUT_F16 && dtype != GYMHIP_OUT_BF16) return fail(GYMHIP_EINVAL, "dtype must be GYMHIP_OUT_F16 or GYMHIP_OUT_BF16");
     const int P = h->cfg.dst_h * h->cfg.dst_w;
     hipStream_t s = (hipStream_t)stream;
-    const int64_t planes = h->cfg.n_envs * h->cfg.n_stack; const int k = h->cfg.n_stack, head = h->head;
-    int split; unsigned grid;
-    if (P % 8 == 0) {
-        materialize_shape(planes, P / 8, &split, &grid);
-        if (dtype == GYMHIP_OUT_BF16) hipLaunchKernelGGL((materialize_nchw_kernel<1, 1>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, head, split);
-        else hipLaunchKernelGGL((materialize_nchw_kernel<1, 0>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, head, split);
-    } else {
-        materialize_shape(planes, P / 4, &split, &grid);
-        if (dtype == GYMHIP_OUT_BF16) hipLaunchKernelGGL((materialize_nchw_kernel<2, 1>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, head, split);
-        else hipLaunchKernelGGL((materialize_nchw_kernel<2, 0>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, head, split);
-    }
-    HIP_TRY(hipGetLastError());
-    return GYMHIP_OK;
+    if (P % 8 == 0) return dtype == GYMHIP_OUT_BF16 ? launch_nchw<1, 1>(h, out, 8, s) : launch_nchw<1, 0>(h, out, 8, s);
+    return dtype == GYMHIP_OUT_BF16 ? launch_nchw<2, 1>(h, out, 4, s) : launch_nchw<2, 0>(h, out, 4, s);
 }
 
 int gymhip_host_env_post_step(int64_t n, const float* reward_in, const uint8_t* done_in, const int32_t* lives_in, int32_t* st_lives,

@@ -57,6 +57,8 @@ struct AtariFrontEndOptions {
                                         // true  = the reference as it runs today: AtariEnv::getObs returns its one cv::Mat by value
                                         // (atari_env.cpp:11-17), a header copy, so both MaxAndSkip buffers alias the same pixels and
                                         // cv::max (atari_wrappers.cpp:30) yields the LAST emulated frame.
+    bool stack_as_written = false;      // true = gymhip_atari_set_stack_view(GYMHIP_STACK_AS_WRITTEN): VecFrameStack + VecNormAndPermute as the
+                                        // reference computes them today ([prev, new, new, new] channels, signed bytes / 255; gymhip.h)
     int n_stack = 4;                    // VecFrameStack
     int src_h = 210, src_w = 160, dst_h = 84, dst_w = 84;
     int device = 0;
@@ -91,6 +93,7 @@ public:
         c.n_stack = opt.n_stack; c.gray_bits = 15; c.clear_on_done = 0;
         if (gymhip_atari_create(&c, opt.device, &pp) != GYMHIP_OK) throw std::runtime_error(gymhip_last_error());
         if (gymhip_atari_set_palette(pp, zrgb256_palette) != GYMHIP_OK) throw std::runtime_error(gymhip_last_error());
+        if (opt.stack_as_written && gymhip_atari_set_stack_view(pp, GYMHIP_STACK_AS_WRITTEN) != GYMHIP_OK) throw std::runtime_error(gymhip_last_error());
         const size_t bytes = (size_t)n * 2 * hw;
         check(hipHostMalloc((void**)&staging, bytes, hipHostMallocDefault), "hipHostMalloc");
         check(hipMalloc((void**)&dev_screens, bytes), "hipMalloc(screens)");

@@ -261,13 +261,20 @@ int gymhip_atari_step_indexed(gymhip_atari* h, const uint8_t* screens, const uin
 /* The stacked observation as a contiguous tensor: channels-last u8 [n_envs][dst_h][dst_w][n_stack], oldest frame in
  * channel 0 (what VecFrameStack returns over WarpFrame's {84,84,1} space, stacked_observation.h:96-99,203-209). */
 int gymhip_atari_materialize_nhwc(gymhip_atari* h, uint8_t* out, void* stream);
-/* Compatibility view: what the reference's VecFrameStack returns AS WRITTEN over a channels-last space.  StackedObservation::update
- * (stacked_observation.h:126-130) rolls the stack left by one channel and then passes stackDim (-1) to stack() where a size is
- * expected (:96-99,129), so the write is y[..., 1:] = x: channel 0 = the previous call's channel 1, channels 1.. = the newest
- * frame (frames 1,2,3,4 after a reset give [3,4,4,4]; straight after reset() the stack is [0,..,0,f] as intended).  The same
- * ring serves both views; this one needs n_stack >= 2 and clear_on_done = 0 (the reference never clears).  Same u8 bytes as the
- * reference's tensor, whose reported dtype is int8 (make_shape<uint8_t> -> kChar, spaces/util.h:60-63). */
-int gymhip_atari_materialize_nhwc_as_written(gymhip_atari* h, uint8_t* out, void* stream);
+/* Which stacked observation the materialise calls below produce.
+ *   GYMHIP_STACK_INTENDED (default): the shift semantics StackedObservation means to implement (SB3's; oldest frame in
+ *     channel 0), uint8 pixels.
+ *   GYMHIP_STACK_AS_WRITTEN: what the reference's code computes today over WarpFrame's channels-last space, bug for bug:
+ *     (ii) StackedObservation::update rolls the stack left by one channel and then passes stackDim (-1) to stack() where a size
+ *     is expected (stacked_observation.h:96-99,126-130), so the write is y[..., 1:] = x: channel 0 = the previous call's
+ *     channel 1, channels 1.. = the newest frame (frames 1,2,3,4 after a reset give [3,4,4,4]; straight after reset() the stack
+ *     is [0,..,0,f]); (i) the buffer's dtype is int8 (make_shape<uint8_t> -> kChar, spaces/util.h:60-63;
+ *     stacked_observation.h:208), so VecNormAndPermute's y / 255 (vec_atari.cpp:74-76) divides SIGNED bytes: a pixel of 200
+ *     comes out as -56 / 255.  _nhwc writes the same bytes either way (read them as int8); the _nchw calls apply the signed
+ *     reading.  Needs n_stack >= 2 (with one channel the reference's stack never changes after reset) and clear_on_done = 0.
+ * The ring itself is the same for both; the view can be switched at any time. */
+enum { GYMHIP_STACK_INTENDED = 0, GYMHIP_STACK_AS_WRITTEN = 1 };
+int gymhip_atari_set_stack_view(gymhip_atari* h, int view);
 /* VecNormAndPermute::observation fused onto the ring (vec_atari.cpp:70-81): f32 [n_envs][n_stack][dst_h][dst_w] = x / 255. */
 int gymhip_atari_materialize_nchw_f32(gymhip_atari* h, float* out, void* stream);
 /* The same tensor for half-precision policies: x / 255 in float32 as vec_atari.cpp:74-76 computes it,

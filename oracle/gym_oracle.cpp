@@ -639,6 +639,13 @@ void oracle_norm_permute(const uint8_t* nhwc, int64_t n, int hw, int k, float* n
         nchw[((size_t)e * k + c) * hw + p] = (float)nhwc[((size_t)e * hw + p) * k + c] / 255.f;
 }
 
+// The same call on the reference's actual buffer: the stacked tensor is int8 (kChar: spaces/util.h:60-63,
+// stacked_observation.h:208), so `y / 255` (vec_atari.cpp:74-76) is a true division of SIGNED bytes in float32.
+void oracle_norm_permute_as_written(const uint8_t* nhwc, int64_t n, int hw, int k, float* nchw) {
+    for (int64_t e = 0; e < n; e++) for (int c = 0; c < k; c++) for (int p = 0; p < hw; p++)
+        nchw[((size_t)e * k + c) * hw + p] = (float)(int8_t)nhwc[((size_t)e * hw + p) * k + c] / 255.f;
+}
+
 int oracle_num_threads() {
 #if defined(_OPENMP)
     return omp_get_max_threads();

@@ -1,7 +1,7 @@
 // Drives gym::AtariFrontEnd<FakeEmulator> (gym_amd/include/gym/atari_frontend.h) like a rollout worker: reset, then T steps
 // with a fixed action stream, and dumps everything the wrapper chain returns so tests/test_cpp_host.py can compare it with
 // the oracle's class-by-class restatement of the reference chain.
-//   usage: atari_frontend_demo <n_envs> <steps> <seed> <terminal_on_life_loss 0|1> <fire_reset 0|1> <out.bin> [max_as_written 0|1]
+//   usage: atari_frontend_demo <n_envs> <steps> <seed> <terminal_on_life_loss 0|1> <fire_reset 0|1> <out.bin> [as_written 0|1]   (as_written: MaxAndSkip aliasing + the as-written stack view)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -19,7 +19,7 @@ int main(int argc, char** argv) {
     o.terminal_on_life_loss = std::atoi(argv[4]) != 0;
     o.fire_reset = std::atoi(argv[5]) != 0;
     o.threads = 4;
-    o.max_as_written = argc == 8 && std::atoi(argv[7]) != 0;
+    o.max_as_written = o.stack_as_written = argc == 8 && std::atoi(argv[7]) != 0;
     uint32_t palette[256];
     for (int k = 0; k < 256; k++) palette[k] = (k & 1) ? 0u : (uint32_t)(FakeEmulator::mix(77 + (uint64_t)k) & 0xFFFFFFu);   // NTSC-table shape: odd entries 0
     std::vector<std::unique_ptr<FakeEmulator>> emus;
@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> u8((size_t)n * K * P), newest((size_t)n * P);
     auto fetch = [&]() {
         if (hipMemcpy(obs.data(), fe.observation(), obs.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) std::exit(4);   // syncs the default stream
-        for (size_t k = 0; k < obs.size(); k++) u8[k] = (uint8_t)std::lrintf(obs[k] * 255.f);
+        for (size_t k = 0; k < obs.size(); k++) u8[k] = (uint8_t)std::lrintf(obs[k] * 255.f);   // as written the values are signed bytes / 255: the cast wraps them back
         for (int64_t e = 0; e < n; e++) std::memcpy(&newest[(size_t)e * P], &u8[((size_t)e * K + (K - 1)) * P], P);
     };
     fe.reset();

@@ -79,6 +79,7 @@ class Oracle:
         l.oracle_framestack_update.argtypes = [_vp, _vp, _i64, C.c_int, C.c_int]
         l.oracle_framestack_update_as_written.argtypes = [_vp, _vp, _i64, C.c_int, C.c_int]
         l.oracle_norm_permute.argtypes = [_vp, _i64, C.c_int, C.c_int, _vp]
+        l.oracle_norm_permute_as_written.argtypes = [_vp, _i64, C.c_int, C.c_int, _vp]
 
     # ---- RNG ------------------------------------------------------------------------------------------
     def cartpole_reset_tape(self, seed, n_envs, episodes, env_offset=0, threads=None):
@@ -179,6 +180,13 @@ class Oracle:
         n, h, w, k = nhwc.shape
         out = np.empty((n, k, h, w), np.float32)
         self.lib.oracle_norm_permute(_p(np.ascontiguousarray(nhwc)), n, h * w, k, _p(out))
+        return out
+
+    def norm_permute_as_written(self, nhwc):
+        """vec_atari.cpp:70-81 on the reference's int8 stack: signed bytes / 255."""
+        n, h, w, k = nhwc.shape
+        out = np.empty((n, k, h, w), np.float32)
+        self.lib.oracle_norm_permute_as_written(_p(np.ascontiguousarray(nhwc.view(np.uint8))), n, h * w, k, _p(out))
         return out
 
     def host_env_post_step(self, rew, done, lives, st, clip):

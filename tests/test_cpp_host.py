@@ -110,9 +110,10 @@ def test_hip_atari_vec_env_is_a_vecenv_and_matches_the_reference_chain(oracle, t
 
 @pytest.mark.gpu
 def test_atari_front_end_max_as_written(oracle, tmp_path):
-    """AtariFrontEndOptions::max_as_written: MaxAndSkipEnv as the reference runs today — its two buffers are cv::Mat headers
-    onto AtariEnv's one frame buffer (atari_env.cpp:11-17 returns `data` by value), so cv::max sees the last emulated frame
-    twice — against the oracle chain with the same aliasing switched on."""
+    """AtariFrontEndOptions::max_as_written + stack_as_written: the chain as the reference runs today — MaxAndSkipEnv's two
+    buffers are cv::Mat headers onto AtariEnv's one frame buffer (atari_env.cpp:11-17 returns `data` by value), so cv::max sees
+    the last emulated frame twice; VecFrameStack writes [prev, new, new, new] into an int8 buffer and VecNormAndPermute divides
+    the signed bytes — against the oracle chain with the same aliasing and the as-written stack restatement."""
     test_atari_front_end_matches_the_reference_chain(oracle, tmp_path, True, True, as_written=True)
 
 
@@ -148,7 +149,7 @@ def test_atari_front_end_matches_the_reference_chain(oracle, tmp_path, life_loss
     for t in range(T):
         a = (np.arange(n) * 7 + t * 3) % 6
         o = chain.step(a)
-        oracle.framestack_update(stack, o["frame"])
+        (oracle.framestack_update_as_written if as_written else oracle.framestack_update)(stack, o["frame"])
         assert np.array_equal(take(n * 7056, np.uint8).reshape(n, 84, 84), o["frame"]), t
         assert np.array_equal(take(n, np.float32), o["reward"]), t
         assert np.array_equal(take(n, np.uint8), o["done"]), t

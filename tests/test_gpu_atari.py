@@ -141,10 +141,10 @@ def test_frame_stack_other_depths(oracle, k):
 
 @pytest.mark.parametrize("k", [2, 3, 4, 8])
 def test_frame_stack_as_written_view(oracle, k):
-    """gymhip_atari_materialize_nhwc_as_written: the reference's VecFrameStack output as written (channel 0 = the previous
-    call's channel 1, channels 1.. = the newest frame; int8), against the oracle's literal restatement — which
-    tests/test_oracle_atari.py pins to the torch calls themselves.  A second reset() starts over; the intended view of the
-    same ring is unaffected."""
+    """gymhip_atari_set_stack_view(GYMHIP_STACK_AS_WRITTEN): the reference's VecFrameStack + VecNormAndPermute outputs as its
+    code computes them today (channel 0 = the previous call's channel 1, channels 1.. = the newest frame; int8 buffer, so
+    / 255 divides signed bytes), against the oracle's literal restatements — which tests/test_oracle_atari.py pins to the
+    torch calls themselves.  A second reset() starts over; switching back gives the intended view of the same ring."""
     from gym_amd.atari import AtariPreprocessor
     n = 3
     pp = AtariPreprocessor(n, n_stack=k)
@@ -155,18 +155,28 @@ def test_frame_stack_as_written_view(oracle, k):
         pp.reset(torch.from_numpy(f0).cuda())
         oracle.framestack_reset(stack, oracle.atari_preprocess(f0))
         oracle.framestack_reset(intended, oracle.atari_preprocess(f0))
-        got = pp.stacked_nhwc_as_written()
-        assert got.dtype == torch.int8 and np.array_equal(got.view(torch.uint8).cpu().numpy(), stack)
-        for t in range(1, k + 4):
-            f = counter_frames(5 + round_, n, t)
-            pp.step(torch.from_numpy(f).cuda())
-            g = oracle.atari_preprocess(f)
-            oracle.framestack_update_as_written(stack, g)
-            oracle.framestack_update(intended, g)
-            assert np.array_equal(pp.stacked_nhwc_as_written().view(torch.uint8).cpu().numpy(), stack), (round_, t)
+        for t in range(0, k + 4):
+            if t:
+                f = counter_frames(5 + round_, n, t)
+                pp.step(torch.from_numpy(f).cuda())
+                g = oracle.atari_preprocess(f)
+                oracle.framestack_update_as_written(stack, g)
+                oracle.framestack_update(intended, g)
+            pp.set_stack_view("as_written")
+            got = pp.stacked_nhwc()
+            assert got.dtype == torch.int8 and np.array_equal(got.view(torch.uint8).cpu().numpy(), stack), (round_, t)
+            want = oracle.norm_permute_as_written(stack)
+            assert want.min() < 0                                                           # pixels >= 128 really come out negative
+            assert np.array_equal(pp.stacked_nchw_f32().cpu().numpy(), want), (round_, t)
+            for dt in (torch.float16, torch.bfloat16):
+                assert torch.equal(pp.stacked_nchw_16(dt).cpu(), torch.from_numpy(want).to(dt)), (round_, t, dt)
+            pp.set_stack_view("intended")
             assert np.array_equal(pp.stacked_nhwc().cpu().numpy(), intended), (round_, t)
+            assert np.array_equal(pp.stacked_nchw_f32().cpu().numpy(), oracle.norm_permute(intended)), (round_, t)
     with pytest.raises(Exception):
-        AtariPreprocessor(n, n_stack=1).stacked_nhwc_as_written()
+        AtariPreprocessor(n, n_stack=1).set_stack_view("as_written")
+    with pytest.raises(Exception):
+        AtariPreprocessor(n, n_stack=4, clear_on_done=True).set_stack_view("as_written")
 
 
 def test_clear_on_done_option():

@@ -122,6 +122,9 @@ def test_frame_stack_as_written_equals_the_literal_torch_calls(oracle, k):
         y[..., -stack_dim:] = x                                   # :129 -> stack(y, x, size = stackDim, false): Slice(-size)
         oracle.framestack_update_as_written(stack, frames[t].reshape(n, H * W))
         assert np.array_equal(y.view(torch.uint8).numpy().reshape(n, H * W, k), stack), t
+        # VecNormAndPermute::observation on that int8 tensor (vec_atari.cpp:74-76): permute, then y / 255 — signed bytes
+        want = (y.permute(0, 3, 1, 2) / 255).numpy()
+        assert want.dtype == np.float32 and np.array_equal(oracle.norm_permute_as_written(stack.reshape(n, H, W, k)), want), t
     if k == 4:
         s = np.zeros((1, 1, 4), np.uint8)
         oracle.framestack_reset(s, np.full((1, 1), 1, np.uint8))
