@@ -222,6 +222,26 @@ def test_config4_full_size_properties():
     assert torch.equal(st[..., -1], lone) and torch.equal(st[..., -2], out) and (st[..., :2] == 0).all()
 
 
+def test_frames_beyond_4_gib_index_arithmetic():
+    """Maximum sizes: 24,000 envs = 4.84 GB of RGB frames, so frame pairs sit beyond byte offsets 2^31 and 2^32 (env 10,652 and
+    env 21,304 straddle them); batch results must equal the small-batch results of the same frames at the first envs, across
+    both boundaries and at the tail — for the preprocess output, the ring after reset + 2 steps, and the NCHW f32 view."""
+    from gym_amd.atari import AtariPreprocessor
+    n, m = 24000, 96
+    g = torch.Generator(device="cuda").manual_seed(3)
+    frames = [torch.randint(0, 256, (n, 2, H, W, 3), dtype=torch.uint8, device="cuda", generator=g) for _ in range(2)]
+    assert frames[0].numel() > (1 << 32)
+    big = AtariPreprocessor(n)
+    out = big.preprocess(frames[0])
+    big.reset(frames[0]); big.step(frames[1]); big.step(frames[0])
+    nhwc, nchw = big.stacked_nhwc(), big.stacked_nchw_f32()
+    for off in (0, (1 << 31) // (2 * H * W * 3) - m // 2, (1 << 32) // (2 * H * W * 3) - m // 2, n - m):
+        small = AtariPreprocessor(m)
+        assert torch.equal(small.preprocess(frames[0][off:off + m].contiguous()), out[off:off + m]), off
+        small.reset(frames[0][off:off + m].contiguous()); small.step(frames[1][off:off + m].contiguous()); small.step(frames[0][off:off + m].contiguous())
+        assert torch.equal(small.stacked_nhwc(), nhwc[off:off + m]) and torch.equal(small.stacked_nchw_f32(), nchw[off:off + m]), off
+
+
 def test_host_env_post_step_lanes(oracle):
     """EpisodicLife + Monitor + ClipReward lanes over scripted (reward, done, lives) streams."""
     from gym_amd.atari import host_env_post_step

@@ -119,3 +119,47 @@ def test_cartpole_lockstep_1m_envs_2000_steps_done_stream_exact(oracle):
     st = eng.state_f64().cpu().numpy()
     assert np.array_equal(st, r["final_obs64"]), f"{int((st != r['final_obs64']).sum())} of {st.size} fp64 state values differ"
     assert eng.poll_error() == 0 and eng.episode_stats()[0] == episodes
+
+
+def test_cartpole_268m_envs_index_arithmetic_beyond_4_gib():
+    """Maximum sizes: 2^28 + 4099 envs on one GPU — the observation and residual arrays are > 4 GiB each, so env rows sit
+    beyond byte offsets 2^31 and 2^32 — with shard equality at the first rows, across both byte boundaries and at the ragged
+    tail, plus the conservation identities.  Counter-RNG resets under TimeLimit(13), so every env resets several times."""
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+    n_big, T, seed, tl = (1 << 28) + 4099, 30, 5, 13
+    w = L.WRAP_TIME_LIMIT | L.WRAP_MONITOR
+    mk = lambda n, off: Engine(EngineConfig(env_kind=L.ENV_CARTPOLE, n_envs=n, precision=L.PRECISION_LOCKSTEP_F64, reset_mode=L.RESET_COUNTER_RNG,
+                                            wrappers=w, max_episode_steps=tl, env_offset=off, seed=seed), 0)
+    big = mk(n_big, 0)
+    big.reset()
+    assert big.obs.numel() * 4 > (1 << 32)
+    shards = [(0, 4096), ((1 << 27) - 2048, 4096), ((1 << 28) - 2048, 4096), (n_big - 4099, 4099)]
+    small = []
+    for off, n in shards:
+        e = mk(n, off)
+        e.reset()
+        assert torch.equal(e.obs, big.obs[off:off + n]), off
+        small.append(e)
+    done_total = len_total = 0.0
+    for t in range(T):
+        a = _actions(n_big, t, 2)
+        big.step(a)
+        d = big.done != 0
+        length, _, _ = big.episode_info()
+        done_total += float(d.sum())
+        len_total += float(length[d].sum(dtype=torch.float64))
+        del d, length
+        for (off, n), e in zip(shards, small):
+            e.step(a[off:off + n].contiguous())
+            assert torch.equal(e.obs, big.obs[off:off + n]) and torch.equal(e.done, big.done[off:off + n]) and \
+                torch.equal(e.reward, big.reward[off:off + n]), (t, off)
+        del a
+    for (off, n), e in zip(shards, small):
+        assert torch.equal(e.state_f64(), big.state_f64()[off:off + n]), off
+    assert big.poll_error() == 0
+    tot = big.episode_stats()
+    assert tot[0] == done_total and tot[2] == len_total
+    running = float(big.counters()["elapsed"].sum(dtype=torch.float64))
+    assert running + len_total == float(n_big) * T
+    assert done_total >= 2.0 * n_big                       # TimeLimit(13) over 30 steps: at least two finished episodes per env
