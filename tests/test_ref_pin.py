@@ -218,3 +218,14 @@ def test_dropin_compiles_against_the_reference_headers_and_describes_itself():
     assert lines[1].split() == ["single", "obs_size=4", "act_n=2"]     # Monitor<TimeLimit<HipCartPoleEnv>>: the reference's own wrapper templates over the single-env face
     f = dict(kv.split("=") for kv in lines[0].split()[1:])
     assert f == {"nEnvs": "64", "obs_size": "4", "obs_type": "6", "ranges": "4", "act_n": "2", "act_size": "2", "seeds": "64", "first_seed": "7", "is_wrapper": "0"}
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref not built (it is built in the container that mounts the reference and travels with the tree)")
+def test_dropin_built_against_the_reference_headers_runs_on_the_gpu():
+    """The same binary on hardware: the reference's own VecEnvWrapper<false> forwarding reset() / step(actions) to HipVecEnv,
+    which was compiled against the reference's base.h — shapes as sync_env.h:107-112 returns them, one stepWait through the wrapper."""
+    r = subprocess.run([DROPIN, "run"], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-1000:]
+    run = [l for l in r.stdout.strip().splitlines() if l.startswith("run ")][-1]
+    assert run.split() == ["run", "obs=[64,4]", "reward=[64,1]", "done=[64,1]", "steps=1"]
