@@ -10,6 +10,7 @@
 #include "wrappers/vec_env/vec_env_wrapper.h"
 #include "wrappers/monitor.h"
 #include "wrappers/time_limit.h"
+#include "wrappers/clip_reward.h"
 
 #include "gym/hip_vec_env.h"
 #include "gym/hip_env.h"
@@ -35,6 +36,27 @@ struct CountingWrapper : gym::VecEnvWrapper<false> {
     StepT stepWait() noexcept override { steps++; return gym::VecEnvWrapper<false>::stepWait(); }
 };
 
+// The REFERENCE's wrapper code running over the single-env face on the GPU: one line per step for tests/test_ref_pin.py to compare
+// with the oracle (reset on done, as sync_env.h:92-100 does).
+template <class Wrapped> static int run_wrapped(std::unique_ptr<Wrapped> env, uint64_t seed, int steps, unsigned n_act) {
+    env->seed(seed);
+    auto s0 = env->reset();
+    std::printf("wreset"); for (double v : s0) std::printf(" %.17g", v); std::printf("\n");
+    for (int t = 0; t < steps; t++) {
+        const int a = (int)(((unsigned)t * 2654435761u >> 7) % n_act);
+        auto r = env->step(a);
+        const int has_tr = r.info.contains("TimeLimit.truncated"), tr = has_tr ? (int)std::any_cast<bool>(r.info["TimeLimit.truncated"]) : 0;
+        const int has_ep = r.info.contains("episode");
+        float ep_r = 0, ep_l = 0;
+        if (has_ep) { auto e = std::any_cast<gym::Result>(r.info["episode"]); ep_r = e.r; ep_l = e.l; }
+        std::printf("wstep %d %d %.9g %d %d %d %d %.9g %.9g", t, a, (double)r.reward, (int)r.done, has_tr, tr, has_ep, (double)ep_r, (double)ep_l);
+        for (double v : r.observation) std::printf(" %.17g", v);
+        std::printf("\n");
+        if (r.done) { auto s = env->reset(); std::printf("wreset"); for (double v : s) std::printf(" %.17g", v); std::printf("\n"); }
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     gym::HipVecEnvOptions o;
     o.env_kind = GYMHIP_ENV_CARTPOLE; o.n_envs = 64; o.max_episode_steps = 500; o.monitor = true;
@@ -48,27 +70,13 @@ int main(int argc, char** argv) {
                 (long long)w.actionSpace()->size()[0], seeds.size(), seeds.empty() ? 0 : seeds[0], (int)w.isWrapper());
     auto single = std::make_unique<WrappedSingle>(gym::TimeLimit<gym::HipCartPoleEnv>::make(std::make_unique<gym::HipCartPoleEnv>(), 500));
     std::printf("single obs_size=%lld act_n=%lld\n", (long long)single->observationSpace()->size()[0], (long long)single->actionSpace()->as<gym::Discrete>()->n);
-    if (argc == 5 && std::string(argv[1]) == "wrapped") {
-        // the REFERENCE's Monitor and TimeLimit code running over the single-env face on the GPU: <seed> <steps> <max_episode_steps>;
-        // one line per step for tests/test_ref_pin.py to compare with the oracle (reset on done, as sync_env.h:92-100 does)
-        const uint64_t seed = std::strtoull(argv[2], nullptr, 10); const int steps = std::atoi(argv[3]); const size_t max_steps = (size_t)std::atoll(argv[4]);
-        auto env = std::make_unique<WrappedSingle>(gym::TimeLimit<gym::HipCartPoleEnv>::make(std::make_unique<gym::HipCartPoleEnv>(), max_steps));
-        env->seed(seed);
-        auto s0 = env->reset();
-        std::printf("wreset"); for (double v : s0) std::printf(" %.17g", v); std::printf("\n");
-        for (int t = 0; t < steps; t++) {
-            const int a = (int)(((unsigned)t * 2654435761u >> 7) % 2u);
-            auto r = env->step(a);
-            const int has_tr = r.info.contains("TimeLimit.truncated"), tr = has_tr ? (int)std::any_cast<bool>(r.info["TimeLimit.truncated"]) : 0;
-            const int has_ep = r.info.contains("episode");
-            float ep_r = 0, ep_l = 0;
-            if (has_ep) { auto e = std::any_cast<gym::Result>(r.info["episode"]); ep_r = e.r; ep_l = e.l; }
-            std::printf("wstep %d %d %.9g %d %d %d %d %.9g %.9g", t, a, (double)r.reward, (int)r.done, has_tr, tr, has_ep, (double)ep_r, (double)ep_l);
-            for (double v : r.observation) std::printf(" %.17g", v);
-            std::printf("\n");
-            if (r.done) { auto s = env->reset(); std::printf("wreset"); for (double v : s) std::printf(" %.17g", v); std::printf("\n"); }
-        }
-        return 0;
+    if (argc == 5 && std::string(argv[1]) == "wrapped")        // CartPole under the reference's Monitor<TimeLimit<>>
+        return run_wrapped<WrappedSingle>(std::make_unique<WrappedSingle>(gym::TimeLimit<gym::HipCartPoleEnv>::make(std::make_unique<gym::HipCartPoleEnv>(), (size_t)std::atoll(argv[4]))),
+                                          std::strtoull(argv[2], nullptr, 10), std::atoi(argv[3]), 2);
+    if (argc == 5 && std::string(argv[1]) == "wrapped_mc") {   // configs[2]'s per-env stack: Monitor<ClipRewardEnv<TimeLimit<MountainCar>>>
+        using TL = gym::TimeLimit<gym::HipMountainCarEnv>; using CR = gym::ClipRewardEnv<TL>; using MO = gym::Monitor<CR, true>;
+        return run_wrapped<MO>(std::make_unique<MO>(std::make_unique<CR>(TL::make(std::make_unique<gym::HipMountainCarEnv>(), (size_t)std::atoll(argv[4])))),
+                               std::strtoull(argv[2], nullptr, 10), std::atoi(argv[3]), 3);
     }
     if (argc > 1 && std::string(argv[1]) == "run") {   // only meaningful where a GPU is visible
         gym::VecEnv<false>& v = w;   // trainers hold the base type; VecEnvWrapper's step(int, Tensor) hides step(actions) by name (vec_env_wrapper.h:49)
