@@ -16,6 +16,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdio>
+#include <limits>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -108,7 +109,12 @@ private:
         c.n_envs = 1; c.seed = seeded ? seed_value : 0;
         c.clip_obs = 10.f; c.clip_reward = 10.f; c.gamma = 0.99f; c.epsilon = 1e-8f;
         if (!ok(gymhip_create(&c, device, nullptr, 0, &h), "gymhip_create")) { h = nullptr; return false; }
-        auto giveUp = [this]() { gymhip_destroy(h); h = nullptr; return false; };
+        auto giveUp = [this]() {
+            gymhip_destroy(h); h = nullptr;
+            if (dev_action) { (void)hipFree(dev_action); dev_action = nullptr; }
+            if (dev_state) { (void)hipFree(dev_state); dev_state = nullptr; }
+            return false;
+        };
         if (KIND == GYMHIP_ENV_CARTPOLE && !ok(seeded ? gymhip_seed_reset_tape(h, seed_value, tape_rows) : gymhip_unseeded_reset_tape(h, tape_rows), "reset tape")) return giveUp();
         if (!ok(gymhip_get_buffers(h, &buf), "gymhip_get_buffers")) return giveUp();
         if (hipMalloc((void**)&dev_action, 4) != hipSuccess || hipMalloc((void**)&dev_state, F * sizeof(double)) != hipSuccess) return giveUp();

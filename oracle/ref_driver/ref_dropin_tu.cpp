@@ -19,6 +19,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "../../tests/cpp/wrapped_probe.h"   // run_wrapped: the same loop the stand-alone mirror's wrappers are driven by
+
 static_assert(std::is_base_of_v<gym::VecEnv<false>, gym::HipVecEnv>, "HipVecEnv derives from the reference's VecEnv<false>");
 static_assert(std::is_same_v<gym::VecEnv<false>::StepT, gym::VecEnvStepReturn<torch::Tensor>>, "reference step type");
 static_assert(!std::is_abstract_v<gym::HipVecEnv>, "every pure virtual of base.h:52-71 is overridden");
@@ -36,27 +38,6 @@ struct CountingWrapper : gym::VecEnvWrapper<false> {
     StepT stepWait() noexcept override { steps++; return gym::VecEnvWrapper<false>::stepWait(); }
 };
 
-// The REFERENCE's wrapper code running over the single-env face on the GPU: one line per step for tests/test_ref_pin.py to compare
-// with the oracle (reset on done, as sync_env.h:92-100 does).
-template <class Wrapped> static int run_wrapped(std::unique_ptr<Wrapped> env, uint64_t seed, int steps, unsigned n_act) {
-    env->seed(seed);
-    auto s0 = env->reset();
-    std::printf("wreset"); for (double v : s0) std::printf(" %.17g", v); std::printf("\n");
-    for (int t = 0; t < steps; t++) {
-        const int a = (int)(((unsigned)t * 2654435761u >> 7) % n_act);
-        auto r = env->step(a);
-        const int has_tr = r.info.contains("TimeLimit.truncated"), tr = has_tr ? (int)std::any_cast<bool>(r.info["TimeLimit.truncated"]) : 0;
-        const int has_ep = r.info.contains("episode");
-        float ep_r = 0, ep_l = 0;
-        if (has_ep) { auto e = std::any_cast<gym::Result>(r.info["episode"]); ep_r = e.r; ep_l = e.l; }
-        std::printf("wstep %d %d %.9g %d %d %d %d %.9g %.9g", t, a, (double)r.reward, (int)r.done, has_tr, tr, has_ep, (double)ep_r, (double)ep_l);
-        for (double v : r.observation) std::printf(" %.17g", v);
-        std::printf("\n");
-        if (r.done) { auto s = env->reset(); std::printf("wreset"); for (double v : s) std::printf(" %.17g", v); std::printf("\n"); }
-    }
-    return 0;
-}
-
 int main(int argc, char** argv) {
     gym::HipVecEnvOptions o;
     o.env_kind = GYMHIP_ENV_CARTPOLE; o.n_envs = 64; o.max_episode_steps = 500; o.monitor = true;
@@ -71,11 +52,11 @@ int main(int argc, char** argv) {
     auto single = std::make_unique<WrappedSingle>(gym::TimeLimit<gym::HipCartPoleEnv>::make(std::make_unique<gym::HipCartPoleEnv>(), 500));
     std::printf("single obs_size=%lld act_n=%lld\n", (long long)single->observationSpace()->size()[0], (long long)single->actionSpace()->as<gym::Discrete>()->n);
     if (argc == 5 && std::string(argv[1]) == "wrapped")        // CartPole under the reference's Monitor<TimeLimit<>>
-        return run_wrapped<WrappedSingle>(std::make_unique<WrappedSingle>(gym::TimeLimit<gym::HipCartPoleEnv>::make(std::make_unique<gym::HipCartPoleEnv>(), (size_t)std::atoll(argv[4]))),
+        return wrapped_probe::run_wrapped<WrappedSingle>(std::make_unique<WrappedSingle>(gym::TimeLimit<gym::HipCartPoleEnv>::make(std::make_unique<gym::HipCartPoleEnv>(), (size_t)std::atoll(argv[4]))),
                                           std::strtoull(argv[2], nullptr, 10), std::atoi(argv[3]), 2);
     if (argc == 5 && std::string(argv[1]) == "wrapped_mc") {   // configs[2]'s per-env stack: Monitor<ClipRewardEnv<TimeLimit<MountainCar>>>
         using TL = gym::TimeLimit<gym::HipMountainCarEnv>; using CR = gym::ClipRewardEnv<TL>; using MO = gym::Monitor<CR, true>;
-        return run_wrapped<MO>(std::make_unique<MO>(std::make_unique<CR>(TL::make(std::make_unique<gym::HipMountainCarEnv>(), (size_t)std::atoll(argv[4])))),
+        return wrapped_probe::run_wrapped<MO>(std::make_unique<MO>(std::make_unique<CR>(TL::make(std::make_unique<gym::HipMountainCarEnv>(), (size_t)std::atoll(argv[4])))),
                                std::strtoull(argv[2], nullptr, 10), std::atoi(argv[3]), 3);
     }
     if (argc > 1 && std::string(argv[1]) == "run") {   // only meaningful where a GPU is visible

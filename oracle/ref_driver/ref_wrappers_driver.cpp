@@ -17,47 +17,10 @@
 #include <cstring>
 #include <vector>
 
+#include "../../tests/cpp/wrappers_probe.h"   // ScriptEnv, run_wrappers, run_csv: the same probe the stand-alone mirror is put through
+
 namespace {
-
-// A scripted env: reward/done come from a tape; observation = steps taken.  Derives from the reference's gym::Env.
-struct ScriptEnv : gym::Env<std::vector<double>, int> {
-    std::vector<float> rew; std::vector<uint8_t> dn; size_t t = 0;
-    ScriptEnv(std::vector<float> r, std::vector<uint8_t> d) : rew(std::move(r)), dn(std::move(d)) {}
-    std::vector<double> reset() noexcept override { return {double(t)}; }
-    StepT step(const int&) noexcept override {
-        size_t i = t % rew.size(); t++;
-        return {{double(t)}, rew[i], dn[i] != 0, {}};
-    }
-};
-
-template <class T> bool rd(FILE* f, T* p, size_t n) { return fread(p, sizeof(T), n, f) == n; }
-
-int run_wrappers(const char* in, const char* out) {
-    FILE* f = fopen(in, "rb"); if (!f) return 2;
-    int64_t L, max_steps, steps, flags;
-    if (!rd(f, &L, 1) || !rd(f, &max_steps, 1) || !rd(f, &steps, 1) || !rd(f, &flags, 1)) return 2;
-    std::vector<float> rew(L); std::vector<uint8_t> dn(L);
-    if (!rd(f, rew.data(), L) || !rd(f, dn.data(), L)) return 2;
-    fclose(f);
-    using TL = gym::TimeLimit<ScriptEnv>;
-    using CR = gym::ClipRewardEnv<TL>;
-    using MO = gym::Monitor<CR, true>;
-    auto env = std::make_unique<MO>(std::make_unique<CR>(std::make_unique<TL>(std::make_unique<ScriptEnv>(rew, dn), std::optional<size_t>((size_t)max_steps))));
-    FILE* o = fopen(out, "wb"); if (!o) return 2;
-    env->reset();
-    for (int64_t s = 0; s < steps; s++) {
-        auto r = env->step(0);
-        float reward = r.reward; uint8_t done = r.done, has_tr = r.info.contains("TimeLimit.truncated"), tr = 0, has_ep = r.info.contains("episode");
-        float ep_r = 0, ep_l = 0;
-        if (has_tr) tr = std::any_cast<bool>(r.info["TimeLimit.truncated"]);
-        if (has_ep) { auto e = std::any_cast<gym::Result>(r.info["episode"]); ep_r = e.r; ep_l = e.l; }
-        fwrite(&reward, 4, 1, o); fwrite(&done, 1, 1, o); fwrite(&has_tr, 1, 1, o); fwrite(&tr, 1, 1, o); fwrite(&has_ep, 1, 1, o);
-        fwrite(&ep_r, 4, 1, o); fwrite(&ep_l, 4, 1, o);
-        if (r.done) env->reset();   // what SyncVecEnv::stepPerWorker does (sync_env.h:92-100)
-    }
-    fclose(o);
-    return 0;
-}
+using wrappers_probe::rd; using wrappers_probe::run_wrappers; using wrappers_probe::run_csv;
 
 int run_rms(const char* in, const char* out) {
     FILE* f = fopen(in, "rb"); if (!f) return 2;
@@ -80,24 +43,6 @@ int run_rms(const char* in, const char* out) {
     return 0;
 }
 
-// Same scripted env as run_wrappers, Monitor constructed with id "env7" and a file name: the CSV the reference writes.
-int run_csv(const char* in, const char* out) {
-    FILE* f = fopen(in, "rb"); if (!f) return 2;
-    int64_t L, max_steps, steps, flags;
-    if (!rd(f, &L, 1) || !rd(f, &max_steps, 1) || !rd(f, &steps, 1) || !rd(f, &flags, 1)) return 2;
-    std::vector<float> rew(L); std::vector<uint8_t> dn(L);
-    if (!rd(f, rew.data(), L) || !rd(f, dn.data(), L)) return 2;
-    fclose(f);
-    using TL = gym::TimeLimit<ScriptEnv>;
-    using MO = gym::Monitor<TL, true>;
-    {
-        auto env = std::make_unique<MO>(std::make_unique<TL>(std::make_unique<ScriptEnv>(rew, dn), std::optional<size_t>((size_t)max_steps)),
-                                        std::numeric_limits<double>::max(), std::string("env7"), std::filesystem::path(out));
-        env->reset();
-        for (int64_t s = 0; s < steps; s++) { auto r = env->step(0); if (r.done) env->reset(); }
-    }   // the writer's ofstream closes here
-    return 0;
-}
 
 // in: int64 F (0 = scalar shape {}, as the return statistics, vec_normalize.h:57), int64 n, float x[n][max(F,1)].
 // out.pt: torch::save of the reference module after one update(x); <out.pt>.bin: mean[F'], var[F'], count as floats.

@@ -1,0 +1,79 @@
+// wrappers_probe.h — one probe, two subjects (like spaces_probe.h).  A scripted env (reward / done from a tape) under
+//     Monitor<ClipRewardEnv<TimeLimit<ScriptEnv>>>      -> per-step reward, done, info["TimeLimit.truncated"], info["episode"]
+//     Monitor<TimeLimit<ScriptEnv>> with a file name    -> the CSV file Monitor's ResultWriter produces
+// compiled (a) by oracle/Makefile `_ref` against the REFERENCE's own common/wrapper.h, wrappers/time_limit.h, clip_reward.h and
+// monitor.h where they lie (oracle/ref_driver/ref_wrappers_driver.cpp), and (b) by tests/cpp/Makefile against the stand-alone
+// mirror gym/wrappers.h (wrappers_mirror_demo.cpp); tests/test_ref_pin.py compares the two outputs byte for byte and against
+// the oracle.  Uses only names both trees define; include the subject's headers first.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <filesystem>
+#include <limits>
+#include <memory>
+#include <optional>
+#include <string>
+#include <vector>
+
+namespace wrappers_probe {
+
+// A scripted env: reward/done come from a tape; observation = steps taken.  Derives from the reference's gym::Env.
+struct ScriptEnv : gym::Env<std::vector<double>, int> {
+    std::vector<float> rew; std::vector<uint8_t> dn; size_t t = 0;
+    ScriptEnv(std::vector<float> r, std::vector<uint8_t> d) : rew(std::move(r)), dn(std::move(d)) {}
+    std::vector<double> reset() noexcept override { return {double(t)}; }
+    StepT step(const int&) noexcept override {
+        size_t i = t % rew.size(); t++;
+        return {{double(t)}, rew[i], dn[i] != 0, {}};
+    }
+};
+
+template <class T> inline bool rd(FILE* f, T* p, size_t n) { return fread(p, sizeof(T), n, f) == n; }
+
+inline int run_wrappers(const char* in, const char* out) {
+    FILE* f = fopen(in, "rb"); if (!f) return 2;
+    int64_t L, max_steps, steps, flags;
+    if (!rd(f, &L, 1) || !rd(f, &max_steps, 1) || !rd(f, &steps, 1) || !rd(f, &flags, 1)) return 2;
+    std::vector<float> rew(L); std::vector<uint8_t> dn(L);
+    if (!rd(f, rew.data(), L) || !rd(f, dn.data(), L)) return 2;
+    fclose(f);
+    using TL = gym::TimeLimit<ScriptEnv>;
+    using CR = gym::ClipRewardEnv<TL>;
+    using MO = gym::Monitor<CR, true>;
+    auto env = std::make_unique<MO>(std::make_unique<CR>(std::make_unique<TL>(std::make_unique<ScriptEnv>(rew, dn), std::optional<size_t>((size_t)max_steps))));
+    FILE* o = fopen(out, "wb"); if (!o) return 2;
+    env->reset();
+    for (int64_t s = 0; s < steps; s++) {
+        auto r = env->step(0);
+        float reward = r.reward; uint8_t done = r.done, has_tr = (r.info.count("TimeLimit.truncated") != 0), tr = 0, has_ep = (r.info.count("episode") != 0);
+        float ep_r = 0, ep_l = 0;
+        if (has_tr) tr = std::any_cast<bool>(r.info["TimeLimit.truncated"]);
+        if (has_ep) { auto e = std::any_cast<gym::Result>(r.info["episode"]); ep_r = e.r; ep_l = e.l; }
+        fwrite(&reward, 4, 1, o); fwrite(&done, 1, 1, o); fwrite(&has_tr, 1, 1, o); fwrite(&tr, 1, 1, o); fwrite(&has_ep, 1, 1, o);
+        fwrite(&ep_r, 4, 1, o); fwrite(&ep_l, 4, 1, o);
+        if (r.done) env->reset();   // what SyncVecEnv::stepPerWorker does (sync_env.h:92-100)
+    }
+    fclose(o);
+    return 0;
+}
+
+// Same scripted env as run_wrappers, Monitor constructed with id "env7" and a file name: the CSV the reference writes.
+inline int run_csv(const char* in, const char* out) {
+    FILE* f = fopen(in, "rb"); if (!f) return 2;
+    int64_t L, max_steps, steps, flags;
+    if (!rd(f, &L, 1) || !rd(f, &max_steps, 1) || !rd(f, &steps, 1) || !rd(f, &flags, 1)) return 2;
+    std::vector<float> rew(L); std::vector<uint8_t> dn(L);
+    if (!rd(f, rew.data(), L) || !rd(f, dn.data(), L)) return 2;
+    fclose(f);
+    using TL = gym::TimeLimit<ScriptEnv>;
+    using MO = gym::Monitor<TL, true>;
+    {
+        auto env = std::make_unique<MO>(std::make_unique<TL>(std::make_unique<ScriptEnv>(rew, dn), std::optional<size_t>((size_t)max_steps)),
+                                        std::numeric_limits<double>::max(), std::string("env7"), std::filesystem::path(out));
+        env->reset();
+        for (int64_t s = 0; s < steps; s++) { auto r = env->step(0); if (r.done) env->reset(); }
+    }   // the writer's ofstream closes here
+    return 0;
+}
+
+}  // namespace wrappers_probe

@@ -26,12 +26,13 @@ def wrapper_script(seed, L):
     return rew, done
 
 
-def run_wrappers(rew, done, max_steps, steps):
+def run_wrappers(rew, done, max_steps, steps, driver=None):
+    """`driver`: another binary that speaks the same protocol (tests/cpp/bin/wrappers_mirror_demo: the stand-alone mirror)."""
     with tempfile.TemporaryDirectory() as d:
         fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
         with open(fin, "wb") as f:
             f.write(np.array([rew.size, max_steps, steps, 7], np.int64).tobytes()); f.write(rew.tobytes()); f.write(done.tobytes())
-        subprocess.run([DRIVER, "wrappers", fin, fout], check=True, capture_output=True)
+        subprocess.run([driver or DRIVER, "wrappers", fin, fout], check=True, capture_output=True)
         return np.fromfile(fout, REC)
 
 
@@ -85,13 +86,13 @@ def run_ckpt_load(in_pt):
     return v[:n], v[n:2 * n], float(v[2 * n])
 
 
-def run_csv(rew, done, max_steps, steps, out_csv):
+def run_csv(rew, done, max_steps, steps, out_csv, driver=None):
     """The reference's Monitor<TimeLimit<scripted env>> constructed with id "env7" and a file name -> its CSV log."""
     with tempfile.TemporaryDirectory() as d:
         fin = os.path.join(d, "in")
         with open(fin, "wb") as f:
             f.write(np.array([rew.size, max_steps, steps, 5], np.int64).tobytes()); f.write(rew.tobytes()); f.write(done.tobytes())
-        subprocess.run([DRIVER, "csv", fin, out_csv], check=True, capture_output=True)
+        subprocess.run([driver or DRIVER, "csv", fin, out_csv], check=True, capture_output=True)
 
 
 def main():

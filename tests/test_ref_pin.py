@@ -130,6 +130,42 @@ def test_monitor_csv_bytes_match_the_reference_writer(oracle, tmp_path):
         assert float("%g" % er) == r and float(el) == l
 
 
+MIRROR_WRAPPERS = os.path.join(os.path.dirname(G), "cpp", "bin", "wrappers_mirror_demo")
+
+
+def test_cpp_wrapper_mirror_equals_the_references_templates(tmp_path):
+    """gym/wrappers.h (stand-alone Wrapper / RewardWrapper / TimeLimit / ClipRewardEnv / Monitor / ResultWriter) under the very
+    probe the reference's own templates were put through (tests/cpp/wrappers_probe.h): per-step reward (sign of zero included),
+    done, info["TimeLimit.truncated"], info["episode"] equal the frozen reference output record for record, and the CSV file is
+    the reference's byte for byte apart from the wall-clock column and the t_start stamp."""
+    assert os.path.exists(MIRROR_WRAPPERS), "build tests/cpp first"
+    g = np.load(os.path.join(G, "ref_wrappers.npz"))
+    rew, done = R.wrapper_script(int(g["script_seed"]), int(g["script_len"]))
+    rec = R.run_wrappers(rew, done, int(g["max_steps"]), len(g["done"]), driver=MIRROR_WRAPPERS)
+    for name in R.REC.names:
+        assert np.ascontiguousarray(rec[name]).tobytes() == np.ascontiguousarray(g[name]).astype(rec[name].dtype).tobytes(), name      # bit patterns: keeps -0.0
+    # the CSV: same script and wrapper stack as tests/golden/ref_monitor.csv
+    rew, done = R.wrapper_script(11, 997)
+    out = tmp_path / "mirror.anything"
+    R.run_csv(rew, done, 13, 1500, str(out), driver=MIRROR_WRAPPERS)
+    mine = open(tmp_path / "mirror.csv", "rb").read().decode()
+    ref = open(os.path.join(G, "ref_monitor.csv"), "rb").read().decode()
+    mh, mb = mine.split("t,r,l", 1); rh, rb = ref.split("t,r,l", 1)
+    assert mh.splitlines()[0].startswith("t_start: ") and mh.splitlines()[1] == rh.splitlines()[1] == "id: env7" and mine.count("\n") == ref.count("\n")
+    for a, b in zip(mb.strip().split("\n"), rb.strip().split("\n")):
+        assert a.split(",")[1:] == b.split(",")[1:]                      # r, l as the reference printed them; t is wall time
+
+
+@pytest.mark.skipif(not HAVE_DRIVER, reason="oracle/_ref not built (needs /root/reference; build container only)")
+def test_cpp_wrapper_mirror_vs_live_reference_driver():
+    assert os.path.exists(MIRROR_WRAPPERS), "build tests/cpp first"
+    for seed, L, max_steps in ((1, 101, 5), (2, 64, 1000), (3, 333, 2), (4, 50, 1)):
+        rew, done = R.wrapper_script(seed, L)
+        a = R.run_wrappers(rew, done, max_steps, 1500)
+        b = R.run_wrappers(rew, done, max_steps, 1500, driver=MIRROR_WRAPPERS)
+        assert a.tobytes() == b.tobytes(), (seed, L, max_steps)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Spaces, Env::seed and the in-tree drop-in: everything of the reference that compiles here without a stand-in header
 # ---------------------------------------------------------------------------------------------------------------------
@@ -231,18 +267,29 @@ def test_dropin_built_against_the_reference_headers_runs_on_the_gpu():
     assert run.split() == ["run", "obs=[64,4]", "reward=[64,1]", "done=[64,1]", "steps=1"]
 
 
+HIP_ENV_DEMO = os.path.join(os.path.dirname(G), "cpp", "bin", "hip_env_demo")
+
+
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref not built (it is built in the container that mounts the reference and travels with the tree)")
+@pytest.mark.parametrize("templates", ["reference", "mirror"])
 @pytest.mark.parametrize("kind,seed,max_steps", [("cartpole", 3, 500), ("cartpole", 11, 9), ("mountaincar", 0, 200), ("mountaincar", 0, 7)])
-def test_reference_monitor_and_timelimit_templates_over_the_gpu_env(oracle, kind, seed, max_steps):
+def test_reference_monitor_and_timelimit_templates_over_the_gpu_env(oracle, kind, seed, max_steps, templates):
     """The REFERENCE's own wrapper code (wrappers/monitor.h, time_limit.h, clip_reward.h — compiled from its headers) around the
     single-env face, stepping on the GPU: Monitor<TimeLimit<HipCartPoleEnv>> and configs[2]'s per-env stack
     Monitor<ClipRewardEnv<TimeLimit<HipMountainCarEnv>>>.  Every double of every CartPole observation (MountainCar: <= 1e-14),
-    rewards, dones, info["TimeLimit.truncated"] and info["episode"] (r, l) equal the oracle's."""
+    rewards, dones, info["TimeLimit.truncated"] and info["episode"] (r, l) equal the oracle's.  "mirror": the same loop
+    (tests/cpp/wrapped_probe.h) with the stand-alone gym/wrappers.h templates instead (tests/cpp/hip_env_demo)."""
     from tests.oracle_lib import CARTPOLE, MOUNTAINCAR, F_CLIP_REWARD, F_MONITOR, F_TIME_LIMIT
     cart = kind == "cartpole"
     steps, n_act = (450, 2) if cart else (900, 3)
-    r = subprocess.run([DROPIN, "wrapped" if cart else "wrapped_mc", str(seed), str(steps), str(max_steps)], capture_output=True, text=True, timeout=240)
+    if templates == "reference":
+        if not os.path.exists(DROPIN):
+            pytest.skip("oracle/_ref not built (it is built in the container that mounts the reference and travels with the tree)")
+        cmd = [DROPIN, "wrapped" if cart else "wrapped_mc", str(seed), str(steps), str(max_steps)]
+    else:
+        assert os.path.exists(HIP_ENV_DEMO), "build tests/cpp first"
+        cmd = [HIP_ENV_DEMO, kind, str(seed), str(steps), str(max_steps)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
     lines = [l.split() for l in r.stdout.strip().splitlines() if l.startswith("w")]
     v = oracle.vec(CARTPOLE if cart else MOUNTAINCAR, 1, F_TIME_LIMIT | F_MONITOR | (0 if cart else F_CLIP_REWARD), max_steps, threads=1)
