@@ -331,3 +331,48 @@ def test_auto_reset_off_stepping_a_finished_env_is_reported_not_simulated():
     assert env.reset(2).shape == (4,)
     s = env.step(a)
     assert s.done[2].item() == 0 and s.reward[2].item() == 1.0 and s.done.sum().item() == 7
+
+
+def test_the_references_own_smoke_scenarios_at_their_sizes(oracle):
+    """test/classic_control.cpp at the sizes it uses: (a) :105-107 — 10 CartPole envs under Monitor + TrainingVecNormRO for 20,000
+    env-steps (2,000 vec steps: a long horizon for the float32 running statistics); (b) :109-112 — 1028 envs for 1e6 env-steps
+    (973 vec steps), where the reference only asserts obs.size(0) == N_env and obs.size(1) == 4 (:85-86) and prints a wall time.
+    Here every step is also compared with the oracle."""
+    from gym_amd.vec_env import HipVecEnv, TrainingVecNormRO
+    # (a)
+    n, T, seed = 10, 2000, 1
+    env = TrainingVecNormRO(HipVecEnv.make("CartPole-v1", n, monitor=True))
+    env.seed(seed)
+    ov = oracle.vec(CARTPOLE, n, F_MONITOR, 0)
+    ov.seed(seed); ov.attach_norm()
+    obs = env.reset()
+    o_obs, _ = ov.norm_reset()
+    assert obs.shape == (n, 4) and np.allclose(obs.cpu().numpy(), o_obs, atol=1e-5)
+    acts = splitmix_actions(3, T, n, 2)
+    episodes = 0
+    for t in range(T):
+        s = env.step(torch.from_numpy(acts[t].astype(np.int64)))
+        r = ov.norm_step(acts[t])
+        assert np.array_equal(s.done.cpu().numpy()[:, 0], r["done"]) and np.array_equal(env.oldObs().cpu().numpy(), r["raw_obs"]), t
+        st = ov.norm_stats()
+        cond = np.maximum(1.0, np.abs(st[:4]) / np.sqrt(st[4:8] + 1e-8))
+        assert (np.abs(s.observation.cpu().numpy() - r["obs"]) <= 1e-5 * cond * np.maximum(1.0, np.abs(r["obs"]))).all(), t
+        assert np.allclose(s.reward.cpu().numpy()[:, 0], r["reward"], rtol=1e-5, atol=1e-6), t
+        episodes += int(r["done"].sum())
+    got, want = env.venv.engine.get_norm_stats(), ov.norm_stats()
+    assert (np.abs(got - want) <= 1e-5 * np.maximum(np.abs(want), 1e-6)).all() and got[8] == want[8] == np.float32(1e-4 + n * (T + 1))
+    assert episodes > 500 and env.venv.engine.episode_stats()[0] == episodes
+    # (b)
+    n, T = 1028, 973
+    env = HipVecEnv.make("CartPole-v1", n, max_episode_steps=500, monitor=True)
+    env.seed(0)
+    ov = oracle.vec(CARTPOLE, n, F_TIME_LIMIT | F_MONITOR, 500)
+    ov.seed(0)
+    obs = env.reset()
+    assert obs.size(0) == n and obs.size(1) == 4 and np.array_equal(obs.cpu().numpy(), ov.reset())
+    acts = splitmix_actions(9, T, n, 2)
+    for t in range(T):
+        s = env.step(torch.from_numpy(acts[t].astype(np.int64)))
+        r = ov.step(acts[t])
+        assert np.array_equal(s.observation.cpu().numpy(), r["obs"]) and np.array_equal(s.done.cpu().numpy()[:, 0], r["done"]), t
+    assert env.engine.poll_error() == 0
