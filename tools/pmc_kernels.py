@@ -20,7 +20,7 @@ KERNELS = {
     "normalize_kernel<2,": ("config3_normalize_kernel", N3 * (8 + 4), N3 * (8 + 4)),
     "atari_preprocess_kernel": ("config4_atari_preprocess_rgb", N4 * 2 * 100800, N4 * 7056),
     "materialize_nchw_kernel<0,": ("config4_materialize_nchw_f32", N4 * 28224, N4 * 28224 * 4),
-    "materialize_nchw_kernel<1, 1>": ("config4_materialize_nchw_bf16", N4 * 28224, N4 * 28224 * 2),
+    "materialize_nchw_kernel<1, 1,": ("config4_materialize_nchw_bf16", N4 * 28224, N4 * 28224 * 2),
 }
 
 
