@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
 
@@ -59,6 +60,36 @@ template <int V, bool NT, bool PIPE> __global__ __launch_bounds__(512) void mix_
     }
 }
 
+
+// Which streams cost what: MASK bit 0 = obs rw, 1 = residual rw, 2 = counter rw, 3 = action r, 4 = reward w, 5 = done w.
+// MERGED: residual and counter live in ONE array of 64-env tiles [64 x 16 B residual | 64 x 4 B counter] (1280 B per tile).
+template <int MASK, bool MERGED> __global__ __launch_bounds__(512) void subset_kernel(f32x4* obs, i32x4* res, const int32_t* __restrict__ act, uint32_t* ctr,
+                                                                                        float* rew, float* done, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 512;
+    struct In { f32x4 o; i32x4 k; int32_t a; uint32_t w; };
+    auto res_ptr = [&](int64_t i) { return MERGED ? (i32x4*)((char*)res + (i >> 6) * 1280 + (i & 63) * 16) : res + i; };
+    auto ctr_ptr = [&](int64_t i) { return MERGED ? (uint32_t*)((char*)res + (i >> 6) * 1280 + 1024 + (i & 63) * 4) : ctr + i; };
+    auto load = [&](int64_t i, In& in) {
+        if (MASK & 1) in.o = ld<true>(obs + i);
+        if (MASK & 2) in.k = ld<true>(res_ptr(i));
+        if (MASK & 8) in.a = ld<true>(act + i);
+        if (MASK & 4) in.w = ld<true>(ctr_ptr(i));
+    };
+    int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x;
+    In cur{}, nxt{};
+    if (i < n) load(i, cur);
+    for (; i < n; i += stride) {
+        if (i + stride < n) load(i + stride, nxt);
+        if (MASK & 1) st<true>(obs + i, cur.o * 1.0001f);
+        if (MASK & 2) st<true>(res_ptr(i), cur.k + 1);
+        const uint32_t w = cur.w + 1u;
+        if (MASK & 4) st<true>(ctr_ptr(i), w);
+        if (MASK & 16) st<true>(rew + i, (float)cur.a + cur.o.x);
+        if (MASK & 32) st<true>(done + i, (float)(w & 1u));
+        cur = nxt;
+    }
+}
+
 template <typename F> static double time_ms(F&& launch, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int i = 0; i < 5; i++) launch();
@@ -85,9 +116,11 @@ int main(int argc, char** argv) {
     const double bytes = 84.0 * n;
     const int reps = 40;
     std::printf("n_envs %lld, slab %p\n", (long long)n, (void*)slab);
-    for (int64_t skew : {(int64_t)0, (int64_t)256, (int64_t)512, (int64_t)1024, (int64_t)2048, (int64_t)4096, (int64_t)8192, (int64_t)16384, (int64_t)32768,
-                         (int64_t)65536, (int64_t)(65536 + 4096), (int64_t)131072, (int64_t)262144, (int64_t)(262144 + 4096 + 256), (int64_t)1048576,
-                         (int64_t)(1048576 + 65536 + 4096 + 256), (int64_t)2097152, (int64_t)(2097152 + 4096)}) {
+    const bool full_sweep = argc > 2;
+    std::vector<int64_t> skews = {0, 4096};
+    if (full_sweep) skews = {0, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 65536 + 4096, 131072, 262144, 262144 + 4096 + 256, 1048576,
+                             1048576 + 65536 + 4096 + 256, 2097152, 2097152 + 4096};
+    for (int64_t skew : skews) {
         char* p[6]; int64_t off = 0;
         for (int k = 0; k < 6; k++) { p[k] = slab + off + k * skew; off += sizes[k]; }
         for (int grid : {2048, 4096}) {
@@ -95,6 +128,29 @@ int main(int argc, char** argv) {
             std::printf("mix V=1 nt pipe  skew %8lld  grid %5d  %.4f ms  %.0f GB/s  %.3f of 8 TB/s\n", (long long)skew, grid, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);
             std::fflush(stdout);
         }
+    }
+
+    {
+        char* p[6]; int64_t off = 0;
+        for (int k = 0; k < 6; k++) { p[k] = slab + off; off += sizes[k]; }
+        char* merged = slab + off;   // n * 20 B fits in the 6 x 4 MiB of skew head-room only for small n: take obs+residual space of a second slab instead
+        char* slab2; CK(hipMalloc(&slab2, n * 20 + 4096)); CK(hipMemset(slab2, 0, n * 20 + 4096));
+        merged = slab2;
+        auto run = [&](const char* name, double bpe, auto kernel, char* resbase) {
+            for (int grid : {2048, 4096}) {
+                const double ms = time_ms([&] { kernel<<<grid, 512>>>((f32x4*)p[0], (i32x4*)resbase, (const int32_t*)p[2], (uint32_t*)p[3], (float*)p[4], (float*)p[5], n); }, reps);
+                std::printf("%-44s grid %5d  %.4f ms  %5.0f B/env  %.0f GB/s  %.3f of 8 TB/s\n", name, grid, ms, bpe, bpe * n / ms / 1e6, bpe * n / ms / 1e6 / 8000.0);
+                std::fflush(stdout);
+            }
+        };
+        run("all six streams (84 B)", 84, subset_kernel<63, false>, p[1]);
+        run("residual + counter merged in 64-env tiles", 84, subset_kernel<63, true>, merged);
+        run("no reward / done writes", 76, subset_kernel<15, false>, p[1]);
+        run("no reward / done / action", 72, subset_kernel<7, false>, p[1]);
+        run("obs + residual only (16-B streams)", 64, subset_kernel<3, false>, p[1]);
+        run("the 4-B streams only", 20, subset_kernel<60, false>, p[1]);
+        run("obs only", 32, subset_kernel<1, false>, p[1]);
+        CK(hipFree(slab2));
     }
     CK(hipDeviceSynchronize());
     return 0;
