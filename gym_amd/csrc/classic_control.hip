@@ -1422,6 +1422,23 @@ static int reset_begin_impl(gymhip_engine* h, void* stream, bool split) {
 }
 int gymhip_reset_begin(gymhip_engine* h, void* stream) { return reset_begin_impl(h, stream, true); }
 
+// A step issues no allocation and no synchronisation, so it can be recorded into a HIP graph — but two of its kernel arguments are
+// host-side per-step state: the step counter that keys COUNTER_RNG resets and the normaliser's statistics slot.  A graph would
+// replay the recorded values (the same reset draws every replay; statistics read from the wrong slot), silently.  Replay-safe is
+// RESET_TAPE (the cursor lives in each env's counter word) without the normaliser; anything else is refused while the stream is
+// capturing.  The legacy default stream cannot capture, so the usual caller pays nothing for the check.
+static int refuse_unsafe_capture(gymhip_engine* h, hipStream_t s) {
+    if (!s) return GYMHIP_OK;
+    const bool host_state = h->norm || (h->cfg.env_kind == KIND_CARTPOLE && h->cfg.reset_mode == GYMHIP_RESET_COUNTER_RNG);
+    if (!host_state) return GYMHIP_OK;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return GYMHIP_OK; }
+    if (st != hipStreamCaptureStatusNone)
+        return fail(GYMHIP_ESTATE, "this engine's step carries host-side per-step state (COUNTER_RNG step counter / normaliser slot): a captured graph would "
+                                   "replay stale values; capture is supported for RESET_TAPE without the normaliser");
+    return GYMHIP_OK;
+}
+
 static int step_begin_impl(gymhip_engine* h, const void* actions, int action_dtype, void* stream, bool split) {
     if (int rc = check_handle(h)) return rc;
     if (!actions) return fail(GYMHIP_EINVAL, "actions is null");
@@ -1429,6 +1446,7 @@ static int step_begin_impl(gymhip_engine* h, const void* actions, int action_dty
     if (!h->did_reset) return fail(GYMHIP_ESTATE, "step before reset");
     if (h->pending_finish) return fail(GYMHIP_ESTATE, "previous *_begin has no matching *_finish");
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = refuse_unsafe_capture(h, s)) return rc;
     StepParams p = make_params(h);
     p.actions = actions;
     if (h->cfg.env_kind == KIND_CARTPOLE) launch_step_kind<KIND_CARTPOLE>(h, p, action_dtype, s); else launch_step_kind<KIND_MOUNTAINCAR>(h, p, action_dtype, s);
