@@ -88,3 +88,31 @@ def test_sharded_normaliser_moments_world2(tmp_path, oracle):
     assert err.max() <= 1e-5, err.max()
     assert (np.abs(r0 - one) <= 1e-6 * np.maximum(np.abs(one), 1e-6)).all()  # independent of the number of shards
     assert np.load(tmp_path / "episodes_2_0.npy")[0] == eps == np.load(tmp_path / "episodes_1_0.npy")[0]
+
+
+@pytest.mark.timeout(300)
+def test_sharded_normaliser_moments_world8_uneven_shards(tmp_path, oracle):
+    """The node size of the headline metric (8 ranks), with an env count that does not divide by 8 (shard_range hands the remainder
+    to the first ranks): every rank holds the same statistics after every step, they equal the 1-rank run to 1e-6 and the
+    single-process oracle to 1e-5, and the episode count is exact."""
+    from tests.oracle_lib import MOUNTAINCAR, F_CLIP_REWARD, F_MONITOR, F_TIME_LIMIT, splitmix_actions
+    n, T, world = 1003, 210, 8
+    for w in (1, world):
+        mp.spawn(_worker, args=(w, _free_port(), n, T, str(tmp_path)), nprocs=w, join=True)
+    full = oracle.vec(MOUNTAINCAR, n, F_TIME_LIMIT | F_CLIP_REWARD | F_MONITOR, 200)
+    full.attach_norm()
+    full.norm_reset()
+    want = [full.norm_stats()]
+    acts = splitmix_actions(5, T, n, 3)
+    eps = 0
+    for t in range(T):
+        eps += int((full.norm_step(acts[t])["done"] != 0).sum())
+        want.append(full.norm_stats())
+    want = np.stack(want)
+    ranks = [np.load(tmp_path / f"stats_{world}_{r}.npy") for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(ranks[0], ranks[r]), r
+    one = np.load(tmp_path / "stats_1_0.npy")
+    assert (np.abs(ranks[0] - want) / np.maximum(np.abs(want), 1e-6)).max() <= 1e-5
+    assert (np.abs(ranks[0] - one) <= 1e-6 * np.maximum(np.abs(one), 1e-6)).all()
+    assert np.load(tmp_path / f"episodes_{world}_0.npy")[0] == eps == np.load(tmp_path / "episodes_1_0.npy")[0] and eps > 0
