@@ -24,6 +24,7 @@
 #include "spaces/box.h"        // the reference's own Box<T> / Discrete (its include root must be on the include path)
 #include "spaces/discrete.h"
 #include "wrappers/vec_env/updateable.h"   // Updateable / Updater
+#include "wrappers/vec_env/vec_env_wrapper.h"
 #if __has_include("boost/algorithm/string.hpp")
 #include "wrappers/vec_env/vec_normalize.h"   // VecNormalizeStateRewardPair (that header needs boost)
 #else
@@ -141,6 +142,21 @@ public:
             if (opt.monitor) out[i]["episode"] = Result{hr.data_ptr<float>()[i], float(hl.data_ptr<int32_t>()[i]), t};
         }
         return out;
+    }
+
+    // Switches the fused normaliser on (what wrapping in VecNormalize<false, isTraining, normReward, normObs> does in the
+    // reference); only before the engine exists, i.e. before the first reset().  Used by gym::HipVecNormalize below.
+    void configureNormalizer(bool is_training, bool norm_reward, bool norm_obs, float clip_obs, float clip_reward, float gamma, float epsilon) {
+        if (h) throw std::runtime_error("HipVecEnv: the normaliser must be configured before the first reset()");
+        opt.training = is_training; opt.norm_reward = norm_reward; opt.norm_obs = norm_obs;
+        opt.clip_obs = clip_obs; opt.clip_rew = clip_reward; opt.gamma = gamma; opt.epsilon = epsilon;
+    }
+    // copies the running statistics of another env (the (main, env, ...) constructor of VecNormalize, vec_normalize.h:60-73)
+    void copyNormStatsFrom(HipVecEnv& other) {
+        if (!hasNorm() || !other.hasNorm() || !ensure() || !other.ensure()) return;
+        std::vector<float> s(16);
+        if (!ok(gymhip_get_norm_stats(other.h, s.data(), other.opt.stream), "gymhip_get_norm_stats")) return;
+        ok(gymhip_set_norm_stats(h, s.data(), opt.stream), "gymhip_set_norm_stats");
     }
 
     // VecNormalize::save / load (vec_normalize.h:79-108): `returns.pt` and `observation.pt` under `dir`, each the archive
@@ -307,6 +323,40 @@ private:
     size_t seed_value = 0;
     std::chrono::high_resolution_clock::time_point t_start;
 };
+
+// gym::VecNormalize<false, isTraining, normReward, normObs> (vec_normalize.h:20-232) as a wrapper CLASS, for source compatibility
+// with code that composes  VecNormalize<false, ...>(std::move(venv), clip_obs, clip_reward, gamma, epsilon)  over a vec env:
+//     auto venv = gym::HipVecEnv::make(o);                                             // was SyncVecEnv<...>::make(envs)
+//     auto env  = std::make_unique<gym::HipTrainingVecNormRO>(std::move(venv));        // was TrainingVecNormRO<false>
+// The wrapper computes nothing itself: it switches the fused normaliser of the HipVecEnv it is given on (so it must get the env
+// before its first reset(), else std::runtime_error) and forwards; reset / stepWait / reset(index) / step(index, .) come from
+// VecEnvWrapper.  Same public surface as the reference class: save / load / oldObs / update (Updateable) / the (main, env, ...)
+// constructor that copies a training env's statistics.
+template <bool isTraining, bool normReward, bool normObs>
+class HipVecNormalize : public VecEnvWrapper<false>, public Updateable<VecNormalizeStateRewardPair<false>> {
+public:
+    explicit HipVecNormalize(std::unique_ptr<VecEnv<false>> env, float clip_obs = 10.f, float clip_reward = 10.f, float gamma = 0.99f, float epsilon = 1e-8f)
+        : VecEnvWrapper<false>(std::move(env)) {
+        hip = dynamic_cast<HipVecEnv*>(this->venv.get());
+        if (!hip) throw std::invalid_argument("HipVecNormalize fuses into a gym::HipVecEnv; got another VecEnv<false>");
+        hip->configureNormalizer(isTraining, normReward, normObs, clip_obs, clip_reward, gamma, epsilon);
+    }
+    HipVecNormalize(VecEnv<false>* main, std::unique_ptr<VecEnv<false>> env, float clip_obs = 10.f, float clip_reward = 10.f, float gamma = 0.99f,
+                    float epsilon = 1e-8f)
+        : HipVecNormalize(std::move(env), clip_obs, clip_reward, gamma, epsilon) {
+        if (auto* trained = dynamic_cast<HipVecNormalize<true, normReward, normObs>*>(main)) hip->copyNormStatsFrom(*trained->engineEnv());
+    }
+    void save(std::string const& dir) { hip->save(dir); }                      // vec_normalize.h:79-92
+    void load(std::string const& dir) { hip->load(dir); }                      // vec_normalize.h:96-108
+    torch::Tensor oldObs() const { return hip->oldObs(); }                     // vec_normalize.h:94
+    torch::Tensor get() const { return hip->normStats(); }                     // the statistics both RunningMeanStd modules hold (vec_normalize.h:75-77): [2F+4] floats
+    void update(VecNormalizeStateRewardPair<false>&& x) override { hip->update(x.state, x.reward); }   // vec_normalize.h:191-206
+    HipVecEnv* engineEnv() { return hip; }
+
+private:
+    HipVecEnv* hip = nullptr;
+};
+using HipTrainingVecNormRO = HipVecNormalize<true, true, true>;               // gym_.h:15-16
 
 // gym_.h:15-16 — TrainingVecNormRO<false> = VecNormalize<false, true, true, true> over a sync vec env
 inline std::unique_ptr<VecEnv<false>> makeTrainingVecNormRO(HipVecEnvOptions o) {

@@ -32,6 +32,7 @@ static_assert(std::is_base_of_v<gym::Env<std::vector<double>, int>, gym::HipCart
 using WrappedSingle = gym::Monitor<gym::TimeLimit<gym::HipCartPoleEnv>, true>;
 
 // a wrapper written against the reference's VecEnvWrapper, as its own VecNormalize / VecFrameStack are (vec_env_wrapper.h:12-55)
+static_assert(std::is_base_of_v<gym::VecEnvWrapper<false>, gym::HipTrainingVecNormRO>, "the normaliser wrapper class derives from the reference's VecEnvWrapper<false>, as VecNormalize does (vec_normalize.h:21)");
 struct CountingWrapper : gym::VecEnvWrapper<false> {
     using gym::VecEnvWrapper<false>::VecEnvWrapper;
     int steps = 0;

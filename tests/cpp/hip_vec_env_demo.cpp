@@ -1,7 +1,7 @@
 // A training-loop-shaped driver of gym::HipVecEnv, modelled on the reference's own smoke test
 // (test/classic_control.cpp:69-99, p_test_run): build the vec env, reset, check shapes, step with a tensor of actions.
 // Prints one line per step so tests/test_cpp_host.py can compare against the CPU oracle.
-//   usage: hip_vec_env_demo <cartpole|mountaincar> <n_envs> <steps> <norm 0|1> [checkpoint_dir]
+//   usage: hip_vec_env_demo <cartpole|mountaincar> <n_envs> <steps> <norm 0|1|2> [checkpoint_dir]     norm 2 = through the gym::HipTrainingVecNormRO wrapper class
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,7 +14,8 @@ int main(int argc, char** argv) {
     const bool cart = !std::strcmp(argv[1], "cartpole");
     const int64_t n = std::atoll(argv[2]);
     const int steps = std::atoi(argv[3]);
-    const bool norm = std::atoi(argv[4]) != 0;
+    const int norm_mode = std::atoi(argv[4]);
+    const bool norm = norm_mode != 0;
 
     std::setvbuf(stdout, nullptr, _IOLBF, 0);
     gym::HipVecEnvOptions o;
@@ -23,7 +24,10 @@ int main(int argc, char** argv) {
     o.max_episode_steps = cart ? 500 : 200;
     o.clip_reward = !cart;
     o.tape_episodes = 4;   // far too few on purpose: the mirror's tape guard must extend the tape (same mt19937 streams) before any env runs out
-    std::unique_ptr<gym::VecEnv<false>> env = norm ? gym::makeTrainingVecNormRO(o) : gym::HipVecEnv::make(o);
+    // norm 2: the reference's composition — a vec env handed to TrainingVecNormRO's constructor (test/classic_control.cpp:105-107)
+    std::unique_ptr<gym::VecEnv<false>> env = norm_mode == 2 ? std::unique_ptr<gym::VecEnv<false>>(std::make_unique<gym::HipTrainingVecNormRO>(gym::HipVecEnv::make(o)))
+                                              : norm ? gym::makeTrainingVecNormRO(o) : gym::HipVecEnv::make(o);
+    gym::HipVecEnv* hv = norm_mode == 2 ? static_cast<gym::HipTrainingVecNormRO*>(env.get())->engineEnv() : static_cast<gym::HipVecEnv*>(env.get());
     auto seeds = env->seed(7);
     if ((int64_t)seeds.size() != n || seeds[1] != 8) return 3;
     const int64_t n_act = env->actionSpace()->as<gym::Discrete>()->n;
@@ -41,7 +45,7 @@ int main(int argc, char** argv) {
         if (!r.reward.defined() || r.reward.size(0) != n || r.reward.size(1) != 1 || r.done.size(1) != 1) return 5;   // sync_env.h:107-112
         std::printf("step %d %lld %.9e %.9e\n", t, (long long)r.done.sum().item<float>(), r.observation.to(torch::kFloat64).sum().item<double>(),
                     r.reward.to(torch::kFloat64).sum().item<double>());
-        if (csv) csv->log(static_cast<gym::HipVecEnv*>(env.get())->infos());
+        if (csv) csv->log(hv->infos());
         if (t == steps / 2) {
             // the per-index step is a stub that returns BUFFERED values (sync_env.h:141-157): [1]-shaped reward / done of that env
             auto one = env->step(3, actions);
@@ -51,17 +55,17 @@ int main(int argc, char** argv) {
         }
         if (t == steps - 1) {
             if (csv) csv->flush();
-            auto infos = static_cast<gym::HipVecEnv*>(env.get())->infos();
+            auto infos = hv->infos();
             int with_ep = 0; double len_sum = 0;
             for (auto& m : infos) if (m.count("episode")) { with_ep++; len_sum += std::any_cast<gym::Result>(m["episode"]).l; }
             std::printf("infos %d %.1f\n", with_ep, len_sum);
-            auto tot = static_cast<gym::HipVecEnv*>(env.get())->episodeStatistics();
+            auto tot = hv->episodeStatistics();
             std::printf("episodes %.0f %.1f %.1f\n", tot[0], tot[1], tot[2]);
         }
     }
     if (argc == 6 && norm) {
         // VecNormalize::save, then ::load into a second, evaluation-mode env (vec_normalize.h:79-108)
-        auto* trained = static_cast<gym::HipVecEnv*>(env.get());
+        auto* trained = hv;
         trained->save(argv[5]);
         o.norm_obs = o.norm_reward = true; o.training = false;
         auto eval_env = std::make_unique<gym::HipVecEnv>(o);

@@ -26,7 +26,7 @@ def _run(env, n, steps, norm, ckpt_dir=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env,norm", [("cartpole", False), ("mountaincar", True)])
+@pytest.mark.parametrize("env,norm", [("cartpole", False), ("mountaincar", True), ("mountaincar", 2)])   # 2 = composed through the gym::HipTrainingVecNormRO wrapper class, as the reference composes TrainingVecNormRO over a vec env
 def test_cpp_training_loop_matches_oracle(oracle, env, norm, tmp_path):
     assert os.path.exists(BIN), "build tests/cpp first (python -c 'import __graft_entry__ as g; g.build()')"
     n, steps = 2048, 260
