@@ -1402,27 +1402,7 @@ int gymhip_download_reset_tape(gymhip_engine* h, float* host_tape, int64_t episo
     return GYMHIP_OK;
 }
 
-static int reset_begin_impl(gymhip_engine* h, void* stream, bool split) {
-    if (int rc = check_handle(h)) return rc;
-    if (h->pending_finish) return fail(GYMHIP_ESTATE, "previous *_begin has no matching *_finish");
-    if (h->cfg.env_kind == KIND_CARTPOLE && h->cfg.reset_mode == GYMHIP_RESET_TAPE && !h->tape)
-        return fail(GYMHIP_ETAPE, "reset_mode TAPE but no reset tape uploaded (gymhip_upload_reset_tape)");
-    hipStream_t s = (hipStream_t)stream;
-    StepParams p = make_params(h);
-    if (h->cfg.env_kind == KIND_CARTPOLE) launch_reset_kind<KIND_CARTPOLE>(h, p, s); else launch_reset_kind<KIND_MOUNTAINCAR>(h, p, s);
-    if (h->norm) {
-        if (split) launch_reduce_partials(h, s);         // the totals are the all-reduce payload
-        else launch_normalize(h, true, s, true);         // unsplit: the normalise kernel folds the partial rows itself
-    }
-    HIP_TRY(hipGetLastError());
-    h->did_reset = true;
-    h->step_counter += 1;
-    h->pending_finish = h->norm && split; h->pending_is_reset = true;
-    return GYMHIP_OK;
-}
-int gymhip_reset_begin(gymhip_engine* h, void* stream) { return reset_begin_impl(h, stream, true); }
-
-// A step issues no allocation and no synchronisation, so it can be recorded into a HIP graph — but two of its kernel arguments are
+// A step (or reset) issues no allocation and no synchronisation, so it can be recorded into a HIP graph — but two of its kernel arguments are
 // host-side per-step state: the step counter that keys COUNTER_RNG resets and the normaliser's statistics slot.  A graph would
 // replay the recorded values (the same reset draws every replay; statistics read from the wrong slot), silently.  Replay-safe is
 // RESET_TAPE (the cursor lives in each env's counter word) without the normaliser; anything else is refused while the stream is
@@ -1438,6 +1418,27 @@ static int refuse_unsafe_capture(gymhip_engine* h, hipStream_t s) {
                                    "replay stale values; capture is supported for RESET_TAPE without the normaliser");
     return GYMHIP_OK;
 }
+
+static int reset_begin_impl(gymhip_engine* h, void* stream, bool split) {
+    if (int rc = check_handle(h)) return rc;
+    if (h->pending_finish) return fail(GYMHIP_ESTATE, "previous *_begin has no matching *_finish");
+    if (h->cfg.env_kind == KIND_CARTPOLE && h->cfg.reset_mode == GYMHIP_RESET_TAPE && !h->tape)
+        return fail(GYMHIP_ETAPE, "reset_mode TAPE but no reset tape uploaded (gymhip_upload_reset_tape)");
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = refuse_unsafe_capture(h, s)) return rc;
+    StepParams p = make_params(h);
+    if (h->cfg.env_kind == KIND_CARTPOLE) launch_reset_kind<KIND_CARTPOLE>(h, p, s); else launch_reset_kind<KIND_MOUNTAINCAR>(h, p, s);
+    if (h->norm) {
+        if (split) launch_reduce_partials(h, s);         // the totals are the all-reduce payload
+        else launch_normalize(h, true, s, true);         // unsplit: the normalise kernel folds the partial rows itself
+    }
+    HIP_TRY(hipGetLastError());
+    h->did_reset = true;
+    h->step_counter += 1;
+    h->pending_finish = h->norm && split; h->pending_is_reset = true;
+    return GYMHIP_OK;
+}
+int gymhip_reset_begin(gymhip_engine* h, void* stream) { return reset_begin_impl(h, stream, true); }
 
 static int step_begin_impl(gymhip_engine* h, const void* actions, int action_dtype, void* stream, bool split) {
     if (int rc = check_handle(h)) return rc;
