@@ -100,6 +100,18 @@ def time_engine(torch, dist, eng, actions, steps, warmup, world, prewarm_max_ste
     return dt, kern_ms
 
 
+def cpu_model():
+    """The host CPU's model name (BASELINE.md's CPU-baseline plan, item 4), or "unknown"."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(seconds_target):
     """CPU oracle (port of the reference's per-env-object loop), bounded samples — BASELINE.md's CPU-baseline plan:
     (0) configs[0] exactly: ONE CartPole env, seed 0, TimeLimit(500), action tape a_t = mt19937(1)() & 1, 5e6 steps, 1 core
@@ -110,7 +122,7 @@ def cpu_baseline(seconds_target):
     import numpy as np
     from tests.oracle_lib import CARTPOLE, F_MONITOR, F_TIME_LIMIT, Oracle, default_threads, splitmix_actions
     o = Oracle()
-    out = {"nproc_affinity": len(os.sched_getaffinity(0)), "os_cpu_count": os.cpu_count(), "threads_all": default_threads()}
+    out = {"nproc_affinity": len(os.sched_getaffinity(0)), "os_cpu_count": os.cpu_count(), "threads_all": default_threads(), "cpu_model": cpu_model()}
     # (0) configs[0]
     T0 = 5_000_000
     tape = (o.mt19937_raw(1, T0) & 1).astype(np.uint8).reshape(T0, 1)
@@ -605,7 +617,7 @@ def main():
                              f"(ASyncVecEnv shape); 1 core: {c['vec_65536_1core']['value']:.3e}; N=1028: {c['vec_1028_1core']['value']:.3e} (1 core) / "
                              f"{c['vec_1028_allcores']['value']:.3e} ({c['vec_1028_allcores']['cores']} cores); configs[0] single env 5e6 steps, 1 core: "
                              f"{c0['value']:.3e} steps/s (golden prefix ok: {c0.get('golden_prefix_ok')}); sched_getaffinity={c['nproc_affinity']}, "
-                             f"os.cpu_count()={c['os_cpu_count']}",
+                             f"os.cpu_count()={c['os_cpu_count']}, cpu={c['cpu_model']}",
                    "detail": c}
         except Exception as e:  # noqa: BLE001
             cpu = {"error": f"{type(e).__name__}: {e}"}
