@@ -240,10 +240,19 @@ template <int KIND> struct CounterWord {
         if (c >= kCursorMask) { atomicOr(error_flag, 2); return 0; }   // cursor field exhausted (2^20 episodes per env)
         return c + 1;
     }
+    __host__ __device__ static uint32_t next_cursor_wrapping(uint32_t c) { return (c + 1u) & kCursorMask; }   // COUNTER_RNG: an episode index, free to wrap
     __host__ __device__ static uint32_t pack(int t, uint32_t cur, bool done, bool trunc) {
         return (done ? 0x80000000u : 0u) | (trunc ? 0x40000000u : 0u) | (cur << S) | (uint32_t)t;
     }
 };
+
+// The statistics slot a kernel that only reads the statistics uses, and the hand-off that lets the publishing kernel find it
+// without any host-side state (so a recorded step replays correctly from a HIP graph): see normalize_kernel.
+__device__ inline const float* stats_reader_slot(const StepParams& p) {
+    const int32_t t = *p.tick_w;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p.tick_r = t;      // nobody reads tick_r in this kernel
+    return p.stats + 16 * (t & 1);
+}
 
 template <int KIND> struct EnvTraits;
 template <> struct EnvTraits<KIND_CARTPOLE> { static constexpr int F = 4; static constexpr float step_reward = 1.0f; };
@@ -460,9 +469,10 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
     double ep[3] = {0.0, 0.0, 0.0};
     float shift[F + 1];
     if constexpr (NORM) {
+        const float* stats_cur = stats_reader_slot(p);
 #pragma unroll
-        for (int f = 0; f < F; f++) shift[f] = p.stats_cur[f];
-        shift[F] = p.stats_cur[2 * F + 1];
+        for (int f = 0; f < F; f++) shift[f] = stats_cur[f];
+        shift[F] = stats_cur[2 * F + 1];
     }
     const ActT* actions = (const ActT*)p.actions;
     const StepBuffers& b = p.buf;
@@ -545,7 +555,8 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
                     if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
                     cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
                 } else {
-                    e = p.step_counter;        // stateless: (seed, env, global step) is unique per reset
+                    e = cursor;                // stateless: (seed, env, the env's episode index) keys the draw; no host-side step counter,
+                    cursor = CounterWord<KIND>::next_cursor_wrapping(cursor);   // so a recorded step replays correctly from a HIP graph
                 }
                 reset_state<KIND, T>(p, i, e, s);
             }
@@ -606,19 +617,24 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepParams p) {
     for (int c = 0; c < NCOL; c++) acc[c] = 0.0;
     float shift[F];
     if constexpr (NORM) {
+        const float* stats_cur = stats_reader_slot(p);
 #pragma unroll
-        for (int f = 0; f < F; f++) shift[f] = p.stats_cur[f];
+        for (int f = 0; f < F; f++) shift[f] = stats_cur[f];
     }
     const StepBuffers& b = p.buf;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * kBlock) {
         T s[F];
         uint32_t cursor = 0;
-        int64_t e = p.step_counter;
-        if (KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE) {
+        int64_t e = 0;
+        if constexpr (KIND == KIND_CARTPOLE) {   // the env's episode index: the tape row, or the counter-RNG key
             cursor = CounterWord<KIND>::cursor(b.counter[i]);
             e = cursor;
-            if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
-            cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
+            if (p.reset_mode == GYMHIP_RESET_TAPE) {
+                if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
+                cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
+            } else {
+                cursor = CounterWord<KIND>::next_cursor_wrapping(cursor);
+            }
         }
         reset_state<KIND, T>(p, i, e, s);
         float o[F];
@@ -678,10 +694,16 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
     Group cur;
     if (tid < ng) load_group(tid, cur);
 
+    // Which of the two ping-pong slots is current is device state, handed over between kernels so that no launch carries a
+    // host-side slot index (a recorded step then replays correctly from a HIP graph):  the kernel that ran before this one in the
+    // stream (step / reset / batch-moments) read the slot from tick_w and copied it into tick_r; every block here reads tick_r,
+    // block 0 publishes into the OTHER slot and then sets tick_w = tick_r + 1.  Within a kernel nobody reads what that kernel writes.
+    const int32_t tick = *q.tick_r;
+    const float* stats_cur = q.stats + 16 * (tick & 1);
     float mean[F], var[F];
 #pragma unroll
-    for (int f = 0; f < F; f++) { mean[f] = q.stats_cur[f]; var[f] = q.stats_cur[F + f]; }
-    float ocount = q.stats_cur[2 * F], rmean = q.stats_cur[2 * F + 1], rvar = q.stats_cur[2 * F + 2], rcount = q.stats_cur[2 * F + 3];
+    for (int f = 0; f < F; f++) { mean[f] = stats_cur[f]; var[f] = stats_cur[F + f]; }
+    float ocount = stats_cur[2 * F], rmean = stats_cur[2 * F + 1], rvar = stats_cur[2 * F + 2], rcount = stats_cur[2 * F + 3];
     // The batch moments: either already reduced (and all-reduced over ranks) in q.moments — the split step — or, for the
     // unsplit single-GPU step, summed here from the step kernel's per-block partial rows by every block redundantly (the rows
     // sit in L2; same function and order as reduce_partials_kernel, so both forms give identical bits).  Saves one launch.
@@ -717,7 +739,8 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
         rcount = tot;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        float* outs[2] = {q.stats_next, q.stats_public};
+        float* outs[2] = {q.stats + 16 * ((tick & 1) ^ 1), q.stats + 32};
+        *q.tick_w = tick + 1;
         for (int k = 0; k < 2; k++) {
             float* o = outs[k];
 #pragma unroll
@@ -773,11 +796,12 @@ __global__ void reset_index_kernel(const StepParams p, int64_t i, float* obs_nor
     const StepBuffers& b = p.buf;
     const bool tape_mode = KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE;
     uint32_t cursor = CounterWord<KIND>::cursor(b.counter[i]);
-    int64_t e = p.step_counter;
+    int64_t e = cursor;
     if (tape_mode) {
-        e = cursor;
         if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
         cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
+    } else if (KIND == KIND_CARTPOLE) {
+        cursor = CounterWord<KIND>::next_cursor_wrapping(cursor);
     }
     T s[F];
     reset_state<KIND, T>(p, i, e, s);
@@ -789,18 +813,22 @@ __global__ void reset_index_kernel(const StepParams p, int64_t i, float* obs_nor
     b.counter[i] = CounterWord<KIND>::pack(0, cursor, false, false);
     if (b.returns) b.returns[i] = 0.f;                                   // vec_normalize.h:182
     if (obs_norm) {                                                      // normalizeObs<true> (vec_normalize.h:118-123)
+        const float* stats_cur = p.stats + 16 * (*p.tick_w & 1);         // a pure reader: no hand-off
 #pragma unroll
         for (int f = 0; f < F; f++)
-            obs_norm[i * F + f] = fminf(fmaxf((o[f] - p.stats_cur[f]) / sqrtf(p.stats_cur[F + f] + epsilon), -clip_obs), clip_obs);
+            obs_norm[i * F + f] = fminf(fmaxf((o[f] - stats_cur[f]) / sqrtf(stats_cur[F + f] + epsilon), -clip_obs), clip_obs);
     }
 }
 
 // Batch moments of caller rows x f32 [rows][width] for Updateable::update (vec_normalize.h:191-206): shifted sums into
 // partial columns col0 .. col0+width-1 (S1) and col0_sq .. (S2); every other column of the row is zeroed.
-__global__ __launch_bounds__(kBlock) void batch_moments_kernel(const float* __restrict__ x, int64_t rows, int width, const float* shift, int col0, int col0_sq,
-                                                               double* partials) {
+__global__ __launch_bounds__(kBlock) void batch_moments_kernel(const float* __restrict__ x, int64_t rows, int width, const float* stats, const int32_t* tick_w,
+                                                               int32_t* tick_r, int stat_off, int col0, int col0_sq, double* partials) {
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     float sh[4] = {0, 0, 0, 0};
+    const int32_t tick = *tick_w;                                   // a reader of the statistics: slot from tick_w, handed on through tick_r
+    if (blockIdx.x == 0 && threadIdx.x == 0) *tick_r = tick;
+    const float* shift = stats + 16 * (tick & 1) + stat_off;
     for (int f = 0; f < width; f++) sh[f] = shift[f];
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (int64_t)gridDim.x * kBlock)
         for (int f = 0; f < width; f++) { const double d = (double)x[r * width + f] - (double)sh[f]; s1[f] += d; s2[f] += d * d; }
@@ -854,7 +882,8 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepParams p, con
                     if (er >= p.tape_episodes) { atomicOr(p.error_flag, 1); er = er % p.tape_episodes; }
                     cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
                 } else {
-                    er = p.step_counter + k;
+                    er = cursor;
+                    cursor = CounterWord<KIND>::next_cursor_wrapping(cursor);
                 }
                 reset_state<KIND, T>(p, i, er, s);
             }
@@ -970,7 +999,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
     size_t state, obs, obs_norm, reward, done, counter, returns;
-    size_t stats /*3 slots*/, moments, partials, ep_partials, ep_totals, ep_totals_global, error_flag, cursor_max, total;
+    size_t stats /*3 slots*/, ticks /*tick_w, tick_r*/, moments, partials, ep_partials, ep_totals, ep_totals_global, error_flag, cursor_max, total;
 };
 
 int obs_dim_of(int kind) { return kind == KIND_CARTPOLE ? 4 : 2; }
@@ -1016,6 +1045,7 @@ Layout make_layout(const gymhip_config& c) {
     L.counter = take(n * 4);
     L.returns = (c.wrappers & GYMHIP_WRAP_NORM_REWARD) ? take(n * 4) : (size_t)-1;
     L.stats = norm ? take(3 * 16 * 4) : (size_t)-1;
+    L.ticks = norm ? take(2 * 4) : (size_t)-1;
     L.moments = take(kMaxCols * 8);
     L.partials = norm ? take((size_t)kMaxGrid * kMaxCols * 8) : (size_t)-1;
     L.ep_partials = take((size_t)kMaxGrid * 4 * 8);
@@ -1052,7 +1082,6 @@ struct gymhip_engine {
     Layout L;
     int grid;
     bool norm;
-    int stats_slot;          // ping-pong slot holding the current running statistics
     float* tape;
     int64_t tape_episodes;
     int tape_source;         // 0 = none / uploaded / device-generated, 1 = drawn on the host with std::mt19937 (can be extended)
@@ -1061,7 +1090,6 @@ struct gymhip_engine {
     bool did_reset;
     bool pending_finish;     // a *_begin with the normaliser on awaits its *_finish
     bool pending_is_reset;
-    int64_t step_counter;    // VecEnv steps taken so far (COUNTER_RNG reset key)
     bool stream_nt;          // step kernel streams with non-temporal accesses (footprint beyond the Infinity Cache)
     double* scratch_dev;     // this device's copy of the static `scratch` array (resolve_scratch)
 
@@ -1080,13 +1108,14 @@ StepParams make_params(gymhip_engine* h) {
     p.max_episode_steps = h->cfg.max_episode_steps;
     p.reset_mode = h->cfg.reset_mode;
     p.gamma = h->cfg.gamma;
-    p.step_counter = h->step_counter;
     p.tape = h->tape;
     p.tape_episodes = h->tape_episodes;
     p.error_flag = h->at<int32_t>(h->L.error_flag);
     p.partials = h->at<double>(h->L.partials);
     p.ep_partials = h->at<double>(h->L.ep_partials);
-    p.stats_cur = h->norm ? h->stats_slot_ptr(h->stats_slot) : nullptr;
+    p.stats = h->norm ? h->stats_slot_ptr(0) : nullptr;
+    p.tick_w = h->at<int32_t>(h->L.ticks);
+    p.tick_r = h->norm ? h->at<int32_t>(h->L.ticks) + 1 : nullptr;
     StepBuffers& b = p.buf;
     b.state = h->at<void>(h->L.state);
     b.obs = h->at<float>(h->L.obs);
@@ -1174,9 +1203,8 @@ int launch_normalize(gymhip_engine* h, bool is_reset, hipStream_t s, bool fold) 
     const bool training = w & GYMHIP_WRAP_NORM_TRAINING;
     NormParams q{};
     q.n = h->cfg.n_envs;
-    q.stats_cur = h->stats_slot_ptr(h->stats_slot);
-    q.stats_next = h->stats_slot_ptr(h->stats_slot ^ 1);
-    q.stats_public = h->stats_slot_ptr(2);
+    q.stats = h->stats_slot_ptr(0);
+    q.tick_w = h->at<int32_t>(h->L.ticks); q.tick_r = h->at<int32_t>(h->L.ticks) + 1;
     q.moments = h->at<double>(h->L.moments);
     if (fold) { q.partials = h->at<double>(h->L.partials); q.rows = h->grid; q.n_local = (double)h->cfg.n_envs; q.moments_out = h->at<double>(h->L.moments); }
     q.ep_totals_global = is_reset ? nullptr : h->at<double>(h->L.ep_totals_global);
@@ -1195,8 +1223,7 @@ int launch_normalize(gymhip_engine* h, bool is_reset, hipStream_t s, bool fold) 
         if (h->stream_nt) hipLaunchKernelGGL((normalize_kernel<2, true>), dim3(h->grid), dim3(kBlock), 0, s, q);
         else hipLaunchKernelGGL((normalize_kernel<2, false>), dim3(h->grid), dim3(kBlock), 0, s, q);
     }
-    h->stats_slot ^= 1;  // the kernel always publishes the (possibly unchanged) statistics into the other slot
-    return GYMHIP_OK;
+    return GYMHIP_OK;   // the kernel always publishes the (possibly unchanged) statistics into the other slot and bumps the device-side tick
 }
 
 }  // namespace
@@ -1227,10 +1254,8 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
     h->L = make_layout(*cfg);
     h->norm = cfg->wrappers & (GYMHIP_WRAP_NORM_OBS | GYMHIP_WRAP_NORM_REWARD);
     h->grid = grid_for(cfg->n_envs, h->norm, cfg->env_kind == KIND_CARTPOLE && cfg->precision == GYMHIP_PRECISION_LOCKSTEP_F64);
-    h->stats_slot = 0;
     h->tape = nullptr; h->tape_episodes = 0; h->tape_source = 0; h->tape_seeded = false; h->tape_seed = 0;
     h->did_reset = false; h->pending_finish = false; h->pending_is_reset = false;
-    h->step_counter = 0;
     // Non-temporal streaming pays only once the per-step footprint (workspace + an int32 action row) no longer fits the
     // 256 MiB Infinity Cache; measured crossover on MI355X between 302 MB (temporal +14 %) and 403 MB (non-temporal +6 %).
     h->stream_nt = kNtDefault && h->L.total + (size_t)cfg->n_envs * 4 > kNtFootprint;
@@ -1402,30 +1427,15 @@ int gymhip_download_reset_tape(gymhip_engine* h, float* host_tape, int64_t episo
     return GYMHIP_OK;
 }
 
-// A step (or reset) issues no allocation and no synchronisation, so it can be recorded into a HIP graph — but two of its kernel arguments are
-// host-side per-step state: the step counter that keys COUNTER_RNG resets and the normaliser's statistics slot.  A graph would
-// replay the recorded values (the same reset draws every replay; statistics read from the wrong slot), silently.  Replay-safe is
-// RESET_TAPE (the cursor lives in each env's counter word) without the normaliser; anything else is refused while the stream is
-// capturing.  The legacy default stream cannot capture, so the usual caller pays nothing for the check.
-static int refuse_unsafe_capture(gymhip_engine* h, hipStream_t s) {
-    if (!s) return GYMHIP_OK;
-    const bool host_state = h->norm || (h->cfg.env_kind == KIND_CARTPOLE && h->cfg.reset_mode == GYMHIP_RESET_COUNTER_RNG);
-    if (!host_state) return GYMHIP_OK;
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return GYMHIP_OK; }
-    if (st != hipStreamCaptureStatusNone)
-        return fail(GYMHIP_ESTATE, "this engine's step carries host-side per-step state (COUNTER_RNG step counter / normaliser slot): a captured graph would "
-                                   "replay stale values; capture is supported for RESET_TAPE without the normaliser");
-    return GYMHIP_OK;
-}
-
+// A step (or reset) issues no allocation and no synchronisation, and every per-step value its kernels need lives on the device —
+// the reset-tape cursor and the counter-RNG episode index in each env's counter word, the normaliser's current slot in the
+// tick pair — so a recorded step replays correctly from a HIP graph (tests/test_gpu_graph_capture.py).
 static int reset_begin_impl(gymhip_engine* h, void* stream, bool split) {
     if (int rc = check_handle(h)) return rc;
     if (h->pending_finish) return fail(GYMHIP_ESTATE, "previous *_begin has no matching *_finish");
     if (h->cfg.env_kind == KIND_CARTPOLE && h->cfg.reset_mode == GYMHIP_RESET_TAPE && !h->tape)
         return fail(GYMHIP_ETAPE, "reset_mode TAPE but no reset tape uploaded (gymhip_upload_reset_tape)");
     hipStream_t s = (hipStream_t)stream;
-    if (int rc = refuse_unsafe_capture(h, s)) return rc;
     StepParams p = make_params(h);
     if (h->cfg.env_kind == KIND_CARTPOLE) launch_reset_kind<KIND_CARTPOLE>(h, p, s); else launch_reset_kind<KIND_MOUNTAINCAR>(h, p, s);
     if (h->norm) {
@@ -1434,7 +1444,6 @@ static int reset_begin_impl(gymhip_engine* h, void* stream, bool split) {
     }
     HIP_TRY(hipGetLastError());
     h->did_reset = true;
-    h->step_counter += 1;
     h->pending_finish = h->norm && split; h->pending_is_reset = true;
     return GYMHIP_OK;
 }
@@ -1447,7 +1456,6 @@ static int step_begin_impl(gymhip_engine* h, const void* actions, int action_dty
     if (!h->did_reset) return fail(GYMHIP_ESTATE, "step before reset");
     if (h->pending_finish) return fail(GYMHIP_ESTATE, "previous *_begin has no matching *_finish");
     hipStream_t s = (hipStream_t)stream;
-    if (int rc = refuse_unsafe_capture(h, s)) return rc;
     StepParams p = make_params(h);
     p.actions = actions;
     if (h->cfg.env_kind == KIND_CARTPOLE) launch_step_kind<KIND_CARTPOLE>(h, p, action_dtype, s); else launch_step_kind<KIND_MOUNTAINCAR>(h, p, action_dtype, s);
@@ -1456,7 +1464,6 @@ static int step_begin_impl(gymhip_engine* h, const void* actions, int action_dty
         else launch_normalize(h, false, s, true);
     }
     HIP_TRY(hipGetLastError());
-    h->step_counter += 1;
     h->pending_finish = h->norm && split; h->pending_is_reset = false;
     return GYMHIP_OK;
 }
@@ -1498,7 +1505,6 @@ int gymhip_rollout(gymhip_engine* h, const uint8_t* action_tape, int64_t k_steps
         else hipLaunchKernelGGL((rollout_kernel<KIND_MOUNTAINCAR, false>), g, bdim, 0, s, p, action_tape, k_steps, rec_done, rec_reward, rec_truncated, rec_obs);
     }
     HIP_TRY(hipGetLastError());
-    h->step_counter += k_steps;
     return GYMHIP_OK;
 }
 
@@ -1570,7 +1576,6 @@ int gymhip_reset_index(gymhip_engine* h, int64_t index, void* stream) {
         else hipLaunchKernelGGL((reset_index_kernel<KIND_MOUNTAINCAR, false>), dim3(1), dim3(64), 0, s, p, index, on, h->cfg.clip_obs, h->cfg.epsilon);
     }
     HIP_TRY(hipGetLastError());
-    h->step_counter += 1;
     return GYMHIP_OK;
 }
 
@@ -1585,18 +1590,18 @@ static int update_norm_stats_impl(gymhip_engine* h, const float* obs_rows, int64
         const int g = (int)(g64 < kDefaultGrid ? g64 : kDefaultGrid);
         // every launch rewrites all kMaxCols columns of partial rows [0, g) and the reduction reads exactly those rows:
         // nothing in `partials` has to start at zero, and rows a larger earlier call left behind are never read
-        hipLaunchKernelGGL(batch_moments_kernel, dim3(g), dim3(kBlock), 0, s, x, rows, width, h->stats_slot_ptr(h->stats_slot) + stat_off, col0, col0_sq, partials);
+        int32_t* ticks = h->at<int32_t>(h->L.ticks);
+        hipLaunchKernelGGL(batch_moments_kernel, dim3(g), dim3(kBlock), 0, s, x, rows, width, (const float*)h->stats_slot_ptr(0), (const int32_t*)ticks, ticks + 1, stat_off,
+                           col0, col0_sq, partials);
         NormParams q{};
         q.n = 0;
-        q.stats_cur = h->stats_slot_ptr(h->stats_slot);
-        q.stats_next = h->stats_slot_ptr(h->stats_slot ^ 1);
-        q.stats_public = h->stats_slot_ptr(2);
+        q.stats = h->stats_slot_ptr(0);
+        q.tick_w = ticks; q.tick_r = ticks + 1;
         q.partials = partials; q.rows = g; q.n_local = (double)rows; q.moments_out = moments;   // the one-block normalise launch folds the rows itself
         q.clip_obs = h->cfg.clip_obs; q.clip_reward = h->cfg.clip_reward; q.epsilon = h->cfg.epsilon;
         q.update_obs = is_obs; q.update_ret = !is_obs;
         if (F == 4) hipLaunchKernelGGL((normalize_kernel<4, false>), dim3(1), dim3(kBlock), 0, s, q);
         else hipLaunchKernelGGL((normalize_kernel<2, false>), dim3(1), dim3(kBlock), 0, s, q);
-        h->stats_slot ^= 1;
         HIP_TRY(hipGetLastError());
         return GYMHIP_OK;
     };
@@ -1643,7 +1648,8 @@ int gymhip_diag_pole_sincos(const double* theta, int64_t n, double* sin_out, dou
 int gymhip_get_norm_stats(gymhip_engine* h, float* host_out, void* stream) {
     if (int rc = check_handle(h)) return rc;
     if (!h->norm || !host_out) return fail(GYMHIP_EINVAL, "engine has no normaliser or host_out is null");
-    HIP_TRY(hipMemcpyAsync(host_out, h->stats_slot_ptr(h->stats_slot), (2 * h->F + 4) * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    // slot 2 is the public copy: every publishing kernel writes it together with the new current slot
+    HIP_TRY(hipMemcpyAsync(host_out, h->stats_slot_ptr(2), (2 * h->F + 4) * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return GYMHIP_OK;
 }

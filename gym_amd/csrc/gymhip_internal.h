@@ -25,7 +25,9 @@ struct StepParams {
     const void* actions;
     const float* tape;       // f32 [tape_episodes][N][4]
     int64_t tape_episodes;
-    const float* stats_cur;  // running statistics (shift for the batch-moment partials) or null
+    const float* stats;      // running statistics, two ping-pong slots of 16 floats (+ the public copy), or null; the current slot is *tick_w & 1
+    const int32_t* tick_w;   // device-side slot hand-off (see normalize_kernel): kernels that only READ the statistics take the slot from
+    int32_t* tick_r;         // tick_w and copy it into tick_r; the kernel that PUBLISHES new statistics reads tick_r and bumps tick_w
     double* partials;        // [grid][16]
     double* ep_partials;     // [grid][4] cumulative episodes / sum return / sum length
     int32_t* error_flag;
@@ -33,15 +35,14 @@ struct StepParams {
     int32_t max_episode_steps;
     int32_t reset_mode;
     float gamma;
-    int64_t step_counter;
     StepBuffers buf;
 };
 
 struct NormParams {
     int64_t n;
-    const float* stats_cur;
-    float* stats_next;
-    float* stats_public;
+    float* stats;            // slots 0 / 1 = ping-pong, slot 2 = the public copy (16 floats each)
+    const int32_t* tick_r;   // the current slot is *tick_r & 1 (the preceding step / reset / batch-moments kernel copied it from tick_w)
+    int32_t* tick_w;         // block 0 publishes into the other slot and then sets *tick_w = *tick_r + 1
     const double* moments;   // reduced batch moments (split step), read when `partials` is null
     const double* partials;  // unsplit step: the step kernel's per-block rows [rows][16], folded in the kernel's prologue
     int rows;

@@ -142,10 +142,9 @@ int gymhip_reset(gymhip_engine* h, void* stream);
 /* VecEnv::step(actions) = stepAsync + stepWait (base.h:56-63; sync_env.h:85-123; vec_normalize.h:159-177).
  * `actions` is a device array of n_envs elements of `action_dtype` (the reference narrows any tensor to int32,
  * tensor_adapter.cpp:22-23).  gymhip_step == gymhip_step_begin + gymhip_step_finish.
- * Stream capture: a step neither allocates nor synchronises.  With GYMHIP_RESET_TAPE and no normaliser it may be recorded into a
- * HIP graph and replayed (the tape cursor lives on the device); with COUNTER_RNG resets or the normaliser two kernel arguments are
- * host-side per-step state, a replay would reuse the recorded values, and the call fails with GYMHIP_ESTATE while its stream is
- * capturing. */
+ * Stream capture: a step neither allocates nor synchronises, and all per-step state (tape cursor / counter-RNG episode index per
+ * env, the normaliser's current statistics slot) lives on the device: gymhip_step / gymhip_reset may be recorded into a HIP graph
+ * and replayed; the caller rewrites its static action buffer between replays. */
 int gymhip_step(gymhip_engine* h, const void* actions, int action_dtype, void* stream);
 /* Split form for sharded runs with the normaliser on: after _begin the `moments` buffer holds this rank's batch
  * moments + episode statistics; the caller all-reduces (sum) it over ranks (RCCL) on `stream`, then calls _finish,

@@ -1,7 +1,6 @@
 """GPU: gymhip_step under HIP graph capture.  A step neither allocates nor synchronises; with host-drawn reset tapes and no
 normaliser all of its per-step state lives on the device, so a recorded step can be replayed — checked against an engine
-stepped eagerly and against the CPU oracle.  Where a replay would silently reuse host-side state (COUNTER_RNG step counter,
-normaliser slot) the call refuses to be captured."""
+stepped eagerly and against the CPU oracle — and so do the counter-RNG episode index and the normaliser's statistics slot."""
 import numpy as np
 import pytest
 import torch
@@ -57,31 +56,59 @@ def test_recorded_step_replays_like_eager_steps(oracle, kind):
     assert graphed.poll_error() == 0 and graphed.episode_stats()[0] == eager.episode_stats()[0] > n
 
 
-@pytest.mark.parametrize("what", ["counter_rng", "normaliser"])
-def test_capture_is_refused_where_a_replay_would_reuse_host_state(what):
+@pytest.mark.parametrize("what", ["counter_rng", "normaliser", "normaliser_split", "cartpole_normaliser_rng"])
+def test_recorded_step_replays_with_device_side_step_state(what):
+    """The two values a step used to take from the host — the step counter that keyed COUNTER_RNG resets and the normaliser's
+    current statistics slot — live on the device (each env's episode index in its counter word; the tick pair), so a step
+    recorded once replays like eager stepping: every output, the running statistics and the fp64 state bit for bit."""
     from gym_amd import _lib as L
     from gym_amd.engine import Engine, EngineConfig
-    n = 512
+    n, T = 5000, 150
     w = L.WRAP_TIME_LIMIT | L.WRAP_MONITOR
-    if what == "normaliser":
-        cfg = EngineConfig(env_kind=L.ENV_MOUNTAINCAR, n_envs=n, precision=L.PRECISION_LOCKSTEP_F64, reset_mode=L.RESET_TAPE,
-                           wrappers=w | L.WRAP_NORM_OBS | L.WRAP_NORM_REWARD | L.WRAP_NORM_TRAINING, max_episode_steps=50)
+    norm = L.WRAP_NORM_OBS | L.WRAP_NORM_REWARD | L.WRAP_NORM_TRAINING
+    if what == "counter_rng":
+        cfg = dict(env_kind=L.ENV_CARTPOLE, reset_mode=L.RESET_COUNTER_RNG, wrappers=w, max_episode_steps=30, seed=5)
+    elif what == "cartpole_normaliser_rng":
+        cfg = dict(env_kind=L.ENV_CARTPOLE, reset_mode=L.RESET_COUNTER_RNG, wrappers=w | norm, max_episode_steps=30, seed=6)
     else:
-        cfg = EngineConfig(env_kind=L.ENV_CARTPOLE, n_envs=n, precision=L.PRECISION_LOCKSTEP_F64, reset_mode=L.RESET_COUNTER_RNG, wrappers=w,
-                           max_episode_steps=50, seed=1)
-    eng = Engine(cfg, 0)
-    eng.reset()
-    a = torch.zeros(n, dtype=torch.int32, device="cuda")
+        cfg = dict(env_kind=L.ENV_MOUNTAINCAR, reset_mode=L.RESET_TAPE, wrappers=w | L.WRAP_CLIP_REWARD | norm, max_episode_steps=40)
+    mk = lambda: Engine(EngineConfig(n_envs=n, precision=L.PRECISION_LOCKSTEP_F64, **cfg), 0)
+    graphed, eager = mk(), mk()
+    split = what == "normaliser_split"
+
+    def step(e, a):
+        if split:
+            e.step_begin(a); e.step_finish()
+        else:
+            e.step(a)
+
+    graphed.reset(); eager.reset()
+    n_act = 2 if cfg["env_kind"] == L.ENV_CARTPOLE else 3
+    g_ = torch.Generator(device="cuda").manual_seed(2)
+    acts = torch.randint(0, n_act, (T, n), dtype=torch.int32, device="cuda", generator=g_)
+    static_actions = acts[0].clone()
     side = torch.cuda.Stream()
     torch.cuda.synchronize()
     with torch.cuda.stream(side):
-        eng.step(a)                             # fine on a non-capturing stream
+        step(graphed, static_actions)
     side.synchronize()
+    step(eager, acts[0])
     g = torch.cuda.CUDAGraph()
-    with pytest.raises(Exception, match="captur"):
-        with torch.cuda.graph(g, stream=side):
-            eng.step(a)
+    with torch.cuda.graph(g, stream=side):
+        step(graphed, static_actions)           # recorded, not executed
+    names = ["obs", "reward", "done", "counter"] + (["obs_norm", "returns", "norm_stats"] if what != "counter_rng" else [])
+    for t in range(1, T):
+        static_actions.copy_(acts[t])
+        g.replay()
+        step(eager, acts[t])
+        torch.cuda.synchronize()
+        for name in names:
+            assert torch.equal(getattr(graphed, name), getattr(eager, name)), (t, name)
+    assert torch.equal(graphed.state_f64(), eager.state_f64())
+    if what != "counter_rng":
+        assert np.array_equal(graphed.get_norm_stats(), eager.get_norm_stats())
+    assert graphed.poll_error() == 0 and graphed.episode_stats()[0] == eager.episode_stats()[0] > n
+    # and eager stepping continues from the replayed state
+    step(graphed, acts[0]); step(eager, acts[0])
     torch.cuda.synchronize()
-    eng.step(a)                                 # and the engine is still usable
-    torch.cuda.synchronize()
-    assert eng.poll_error() == 0
+    assert torch.equal(graphed.obs, eager.obs) and torch.equal(graphed.counter, eager.counter)
