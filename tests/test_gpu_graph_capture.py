@@ -112,3 +112,30 @@ def test_recorded_step_replays_with_device_side_step_state(what):
     step(graphed, acts[0]); step(eager, acts[0])
     torch.cuda.synchronize()
     assert torch.equal(graphed.obs, eager.obs) and torch.equal(graphed.counter, eager.counter)
+
+
+def test_counter_rng_resets_equal_a_tape_filled_by_the_same_generator():
+    """With the counter-RNG draw keyed by (seed, global env index, the env's episode index) the in-kernel generator and a device
+    tape filled by the same generator (gymhip_generate_reset_tape) are two routes to the same reset states: an engine in
+    COUNTER_RNG mode and one in TAPE mode over that tape produce identical streams — a cross-check of the tape gather, the cursor
+    bookkeeping and the hash, including a sharded engine (env_offset) and a second reset()."""
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+    n, T, seed, off = 6000, 260, 12, 1000
+    w = L.WRAP_TIME_LIMIT | L.WRAP_MONITOR
+    mk = lambda mode: Engine(EngineConfig(env_kind=L.ENV_CARTPOLE, n_envs=n, precision=L.PRECISION_LOCKSTEP_F64, reset_mode=mode, wrappers=w,
+                                          max_episode_steps=25, env_offset=off, seed=seed), 0)
+    rng, tape = mk(L.RESET_COUNTER_RNG), mk(L.RESET_TAPE)
+    tape.generate_reset_tape(T + 8)
+    rng.reset(); tape.reset()
+    assert torch.equal(rng.obs, tape.obs)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for t in range(T):
+        a = torch.randint(0, 2, (n,), dtype=torch.int32, device="cuda", generator=g)
+        rng.step(a); tape.step(a)
+        assert torch.equal(rng.obs, tape.obs) and torch.equal(rng.done, tape.done) and torch.equal(rng.counter, tape.counter), t
+        if t == T // 2:
+            rng.reset(); tape.reset()                 # a second VecEnv::reset(): both continue from each env's episode index
+            assert torch.equal(rng.obs, tape.obs) and torch.equal(rng.counter, tape.counter)
+    assert torch.equal(rng.state_f64(), tape.state_f64())
+    assert rng.poll_error() == 0 and tape.poll_error() == 0 and rng.episode_stats()[0] == tape.episode_stats()[0] > 5 * n
