@@ -506,15 +506,16 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
     // resets 0.282 -> 0.270 ms; TAPE resets unchanged at 0.284 ms — there the reset-tape gather's over-fetch (a 16-B row
     // per done env drags in a whole memory burst) sets the time, not latency.  Issuing the gather BEFORE the next loads
     // (so that, with the in-order vmcnt counter, its wait would not cover them) was tried and is slower for both.
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * p.lanes;
+    const int64_t first = (int)threadIdx.x < p.lanes ? (int64_t)blockIdx.x * p.lanes + threadIdx.x : p.n;   // threads beyond `lanes` own no env
+    int64_t i = first;
     Inputs cur, nxt;
     if (i < p.n) issue_loads(i, cur);
     for (; i < p.n; i += stride) {
 #if GYMHIP_PIPE
         if (i + stride < p.n) issue_loads(i + stride, nxt);
 #else
-        if (i != (int64_t)blockIdx.x * kBlock + threadIdx.x) issue_loads(i, cur);
+        if (i != first) issue_loads(i, cur);
 #endif
         T s[F];
         if constexpr (LOCKSTEP) {
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepParams p) {
         for (int f = 0; f < F; f++) shift[f] = stats_cur[f];
     }
     const StepBuffers& b = p.buf;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * kBlock) {
+    for (int64_t i = (int)threadIdx.x < p.lanes ? (int64_t)blockIdx.x * p.lanes + threadIdx.x : p.n; i < p.n; i += (int64_t)gridDim.x * p.lanes) {
         T s[F];
         uint32_t cursor = 0;
         int64_t e = 0;
@@ -850,7 +851,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepParams p, con
     const bool clip = p.wrappers & GYMHIP_WRAP_CLIP_REWARD;
     const bool tape_mode = KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE;
     double ep[3] = {0.0, 0.0, 0.0};
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * kBlock) {
+    for (int64_t i = (int)threadIdx.x < p.lanes ? (int64_t)blockIdx.x * p.lanes + threadIdx.x : p.n; i < p.n; i += (int64_t)gridDim.x * p.lanes) {
         T s[F];
         if constexpr (LOCKSTEP) load_state<F>(b, i, s); else load_obs(b.obs, i, s);
         const uint32_t w = b.counter[i];
@@ -1014,12 +1015,25 @@ bool valid_config(const gymhip_config* c) {
     return true;
 }
 
-int grid_for(int64_t n, bool norm, bool cartpole_lockstep) {
+// Launch shape of the step / reset / rollout kernels: `grid` workgroups of kBlock threads of which the first `lanes` own envs.
+int grid_for(int64_t n, bool norm, bool cartpole_lockstep, int* lanes) {
+    *lanes = kBlock;
     int64_t cap = (!norm && cartpole_lockstep) ? kPlainGrid : kDefaultGrid;
     if (const char* e = getenv("GYMHIP_GRID")) { int v = atoi(e); if (v > 0 && v <= kMaxGrid) return (int)std::min<int64_t>(v, (n + kBlock - 1) / kBlock); }
+    // Fewer than 256 full workgroups (BASELINE configs[1]: 65,536 envs = 128 x 512): spread the envs over up to 256 workgroups with
+    // fewer active waves each, so that every CU takes part — these sizes are latency-bound, and one wave per SIMD on 256 CUs beats
+    // two per SIMD on 128 (measured with a 256-thread build: step 4.47 -> 4.22 us, 500-step rollout 0.867 -> 0.762 us per step).
+    const int64_t one_per_thread = (n + kBlock - 1) / kBlock;
+    // (Not with the normaliser: its second kernel folds one partial row per workgroup, and more rows cost more than the spreading
+    // gains — config 3 at 65,536 envs: 9.4 us with 128 workgroups, 10.0 with 256.)
+    if (one_per_thread < 256 && !norm) {
+        int64_t per_block = (n + 255) / 256;
+        per_block = std::min<int64_t>(kBlock, std::max<int64_t>(64, (per_block + 63) / 64 * 64));
+        *lanes = (int)per_block;
+        return (int)((n + per_block - 1) / per_block);
+    }
     // One env per thread until every CU has a block (256); then up to 8 envs per thread before the grid grows to its cap: at
     // the 131,072 .. 1 M envs per GPU of BASELINE configs[2] fewer blocks mean fewer partial rows for the normalise kernel to fold.
-    const int64_t one_per_thread = (n + kBlock - 1) / kBlock;
     if (one_per_thread <= 256) return (int)one_per_thread;
     const int64_t g = (n + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8);
     return (int)std::min<int64_t>(cap, std::max<int64_t>(256, g));
@@ -1087,6 +1101,7 @@ struct gymhip_engine {
     int tape_source;         // 0 = none / uploaded / device-generated, 1 = drawn on the host with std::mt19937 (can be extended)
     bool tape_seeded;        // host-drawn tape: were the envs seeded (seed + index) or default-constructed
     uint64_t tape_seed;
+    int lanes;               // threads per workgroup that own envs in the step / reset / rollout kernels (grid_for)
     bool did_reset;
     bool pending_finish;     // a *_begin with the normaliser on awaits its *_finish
     bool pending_is_reset;
@@ -1108,6 +1123,7 @@ StepParams make_params(gymhip_engine* h) {
     p.max_episode_steps = h->cfg.max_episode_steps;
     p.reset_mode = h->cfg.reset_mode;
     p.gamma = h->cfg.gamma;
+    p.lanes = h->lanes;
     p.tape = h->tape;
     p.tape_episodes = h->tape_episodes;
     p.error_flag = h->at<int32_t>(h->L.error_flag);
@@ -1253,7 +1269,7 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
     h->F = obs_dim_of(cfg->env_kind);
     h->L = make_layout(*cfg);
     h->norm = cfg->wrappers & (GYMHIP_WRAP_NORM_OBS | GYMHIP_WRAP_NORM_REWARD);
-    h->grid = grid_for(cfg->n_envs, h->norm, cfg->env_kind == KIND_CARTPOLE && cfg->precision == GYMHIP_PRECISION_LOCKSTEP_F64);
+    h->grid = grid_for(cfg->n_envs, h->norm, cfg->env_kind == KIND_CARTPOLE && cfg->precision == GYMHIP_PRECISION_LOCKSTEP_F64, &h->lanes);
     h->tape = nullptr; h->tape_episodes = 0; h->tape_source = 0; h->tape_seeded = false; h->tape_seed = 0;
     h->did_reset = false; h->pending_finish = false; h->pending_is_reset = false;
     // Non-temporal streaming pays only once the per-step footprint (workspace + an int32 action row) no longer fits the

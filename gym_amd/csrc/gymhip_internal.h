@@ -35,6 +35,8 @@ struct StepParams {
     int32_t max_episode_steps;
     int32_t reset_mode;
     float gamma;
+    int32_t lanes;           // threads of each workgroup that own envs (a multiple of 64, <= the block size): small env counts are spread
+                             // over more workgroups than n / block would give, so that every CU gets one (the rest of the block idles)
     StepBuffers buf;
 };
 
