@@ -1,14 +1,14 @@
 // wrappers.h — stand-alone mirror of the reference's PER-ENV wrapper API, for code that composes single envs the way the
 // reference does (e.g. gym::Monitor<gym::TimeLimit<gym::HipCartPoleEnv>>) outside the reference tree:
 //     Wrapper / ActionWrapper / RewardWrapper / ObservationWrapper      common/wrapper.h:85-229
+//     ObservationWrapper2, WrapperUnroll, lastType / NthType            common/wrapper.h:231-275, 26-81
 //     TimeLimit                                                         wrappers/time_limit.h:13-45
 //     ClipRewardEnv                                                     wrappers/clip_reward.h:13-26
 //     Monitor, ResultWriter, MonitorWithEarlyReset                      wrappers/monitor.h:20-123, gym_.h:18-19
 // Same names, template parameters, member signatures and observable behaviour (including what is written to stderr and to the
 // CSV file); tests/test_ref_pin.py runs the same scripted env under these templates and under the reference's own (compiled from
 // its headers) and compares every output.  Inside the reference tree (GYMHIP_USE_REFERENCE_HEADERS) this header only includes
-// the reference's files.  Not mirrored: WrapperUnroll and ObservationWrapper2 (common/wrapper.h:32-81,231-275), which only the
-// reference's minigrid / dm_lab envs use.
+// the reference's files.
 // Batches do not go through these: gym::HipVecEnv fuses TimeLimit / ClipReward / Monitor into the step kernel.
 #pragma once
 #ifdef GYMHIP_USE_REFERENCE_HEADERS
@@ -24,6 +24,7 @@
 #include <numeric>
 #include <optional>
 #include <sstream>
+#include <tuple>
 
 #include "gym/monitor_csv.h"
 #include "gym/vec_env.h"
@@ -112,6 +113,67 @@ public:
     ObservationT reset() noexcept override { return observation(this->m_Env->reset()); }
     StepT step(StepT&& resp) noexcept override { return {observation(std::move(resp.observation)), resp.reward, resp.done, resp.info}; }
     ObservationT reset(ObservationT&& x) noexcept override { return observation(std::move(x)); }
+};
+
+// wrapper.h:231-275.  An observation wrapper whose OUTPUT type is not the inner env's observation type (FlatObs-style
+// adapters: vector<double> -> tensor, image -> vector<float> ...).  The inner env is shared, not owned; wrapped() hands it out.
+// The && forms convert a result that was computed elsewhere.
+template <typename EnvT, typename OutputT>
+class ObservationWrapper2 : public Env<OutputT, typename EnvT::ActionT> {
+public:
+    ObservationWrapper2(const std::shared_ptr<Space>& obsSpace, std::shared_ptr<EnvT> env) : m_Env(std::move(env)) {
+        this->m_ObservationSpace = obsSpace;
+        this->m_ActionSpace = m_Env->actionSpace();
+    }
+    virtual OutputT observation(typename EnvT::ObservationT&&) const noexcept = 0;
+
+    StepResponse<OutputT> step(typename EnvT::ActionT const& action) noexcept override { return step(m_Env->step(action)); }
+    StepResponse<OutputT> step(typename EnvT::StepT&& resp) noexcept { return {observation(std::move(resp.observation)), resp.reward, resp.done, resp.info}; }
+    OutputT reset() noexcept override { return observation(m_Env->reset()); }
+    OutputT reset(typename EnvT::ObservationT&& x) noexcept { return observation(std::move(x)); }
+
+    void render() override { m_Env->render(); }
+    std::string info() override { return m_Env->info(); }
+    void seed(std::optional<uint64_t> const& seed) noexcept override { m_Env->seed(seed); }
+    EnvT* wrapped() { return m_Env.get(); }
+
+protected:
+    std::shared_ptr<EnvT> m_Env;
+};
+
+template <class... Stages> using lastType = std::tuple_element_t<sizeof...(Stages) - 1, std::tuple<Stages...>>;   // wrapper.h:26-30
+template <size_t I, class... Stages> using NthType = std::tuple_element_t<I, std::tuple<Stages...>>;
+
+// wrapper.h:32-81.  A wrapper chain resolved at compile time and held BY VALUE in a tuple: stage 0 is an env (reset(), step(action)),
+// every later stage is a wrapper built for its transformation only (the (obsSpace, actSpace) constructors above) whose
+// reset(Obs&&) / step(StepT&&) forms are applied in order.  Types and spaces are the last stage's.  render<I>() calls stage I's
+// _render(), as in the reference (none of the wrappers here has one; its minigrid envs do).
+template <class... Stages>
+struct WrapperUnroll : Env<typename lastType<Stages...>::ObservationT, typename lastType<Stages...>::ActionT, typename lastType<Stages...>::StepT> {
+    using StepT = typename lastType<Stages...>::StepT;
+    using ActionT = typename lastType<Stages...>::ActionT;
+    using ObservationT = typename lastType<Stages...>::ObservationT;
+    static constexpr size_t kStages = sizeof...(Stages);
+
+    std::tuple<Stages...> wrappers;
+
+    WrapperUnroll(Stages... stages) : wrappers(std::forward<Stages>(stages)...) {
+        this->m_ObservationSpace = std::get<kStages - 1>(wrappers).observationSpace();
+        this->m_ActionSpace = std::get<kStages - 1>(wrappers).actionSpace();
+    }
+
+    template <size_t N> ObservationT wrap(ObservationT&& x) {   // stages N, N+1, ... applied to a reset observation
+        if constexpr (N < kStages) return wrap<N + 1>(std::get<N>(wrappers).reset(std::move(x)));
+        else return std::move(x);
+    }
+    template <size_t N> StepT wrap(StepT&& x) {                 // ... and to a step result
+        if constexpr (N < kStages) return wrap<N + 1>(std::get<N>(wrappers).step(std::move(x)));
+        else return std::move(x);
+    }
+    template <size_t I> void render() { std::get<I>(wrappers)._render(); }
+
+    ObservationT reset() noexcept override { return wrap<1>(std::get<0>(wrappers).reset()); }
+    StepT step(ActionT const& action) noexcept override { return wrap<1>(std::get<0>(wrappers).step(action)); }
 };
 
 // time_limit.h:13-45.  The counter runs on the wrapper's own steps; at maxEpisodeSteps the episode ends and

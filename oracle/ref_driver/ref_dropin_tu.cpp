@@ -55,6 +55,11 @@ int main(int argc, char** argv) {
     if (argc == 5 && std::string(argv[1]) == "wrapped")        // CartPole under the reference's Monitor<TimeLimit<>>
         return wrapped_probe::run_wrapped<WrappedSingle>(std::make_unique<WrappedSingle>(gym::TimeLimit<gym::HipCartPoleEnv>::make(std::make_unique<gym::HipCartPoleEnv>(), (size_t)std::atoll(argv[4]))),
                                           std::strtoull(argv[2], nullptr, 10), std::atoi(argv[3]), 2);
+    if (argc == 5 && std::string(argv[1]) == "wrapped_narrowed") {   // the same stack behind the reference's ObservationWrapper2 (vector<double> -> vector<float>)
+        using FO = wrapped_probe::FloatObs<WrappedSingle>;
+        return wrapped_probe::run_wrapped<FO>(std::make_unique<FO>(std::make_shared<WrappedSingle>(gym::TimeLimit<gym::HipCartPoleEnv>::make(std::make_unique<gym::HipCartPoleEnv>(), (size_t)std::atoll(argv[4])))),
+                                              std::strtoull(argv[2], nullptr, 10), std::atoi(argv[3]), 2);
+    }
     if (argc == 5 && std::string(argv[1]) == "wrapped_mc") {   // configs[2]'s per-env stack: Monitor<ClipRewardEnv<TimeLimit<MountainCar>>>
         using TL = gym::TimeLimit<gym::HipMountainCarEnv>; using CR = gym::ClipRewardEnv<TL>; using MO = gym::Monitor<CR, true>;
         return wrapped_probe::run_wrapped<MO>(std::make_unique<MO>(std::make_unique<CR>(TL::make(std::make_unique<gym::HipMountainCarEnv>(), (size_t)std::atoll(argv[4])))),

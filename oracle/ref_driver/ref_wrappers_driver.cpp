@@ -6,6 +6,7 @@
 //
 // usage: ref_wrappers_driver wrappers <in> <out>   |   ref_wrappers_driver rms <in> <out>
 //        ref_wrappers_driver csv <in> <out.csv>            the reference's Monitor with a ResultWriter file (monitor.h:20-35,44-50,93-94)
+//        ref_wrappers_driver unroll <in> <out>             the reference's WrapperUnroll and ObservationWrapper2 (common/wrapper.h:32-81,231-275)
 //        ref_wrappers_driver ckpt_save <in.bin> <out.pt>   the reference's torch::save(RunningMeanStd) after updates (vec_normalize.h:79-92)
 //        ref_wrappers_driver ckpt_load <in.pt> <out.bin>   the reference's torch::load(RunningMeanStd) (vec_normalize.h:96-108)
 #include "wrappers/time_limit.h"
@@ -20,7 +21,7 @@
 #include "../../tests/cpp/wrappers_probe.h"   // ScriptEnv, run_wrappers, run_csv: the same probe the stand-alone mirror is put through
 
 namespace {
-using wrappers_probe::rd; using wrappers_probe::run_wrappers; using wrappers_probe::run_csv;
+using wrappers_probe::rd; using wrappers_probe::run_wrappers; using wrappers_probe::run_csv; using wrappers_probe::run_unroll;
 
 int run_rms(const char* in, const char* out) {
     FILE* f = fopen(in, "rb"); if (!f) return 2;
@@ -81,10 +82,11 @@ int run_ckpt_load(const char* in, const char* out) {
 }  // namespace
 
 int main(int argc, char** argv) {
-    if (argc != 4) { fprintf(stderr, "usage: %s wrappers|rms|csv|ckpt_save|ckpt_load <in> <out>\n", argv[0]); return 1; }
+    if (argc != 4) { fprintf(stderr, "usage: %s wrappers|rms|csv|unroll|ckpt_save|ckpt_load <in> <out>\n", argv[0]); return 1; }
     if (!strcmp(argv[1], "wrappers")) return run_wrappers(argv[2], argv[3]);
     if (!strcmp(argv[1], "rms")) return run_rms(argv[2], argv[3]);
     if (!strcmp(argv[1], "csv")) return run_csv(argv[2], argv[3]);
+    if (!strcmp(argv[1], "unroll")) return run_unroll(argv[2], argv[3]);
     if (!strcmp(argv[1], "ckpt_save")) return run_ckpt_save(argv[2], argv[3]);
     if (!strcmp(argv[1], "ckpt_load")) return run_ckpt_load(argv[2], argv[3]);
     return 1;

@@ -42,10 +42,14 @@ template <class EnvT> int run(long long seed, int steps, int n_act) {
 }
 
 int main(int argc, char** argv) {
-    if (argc != 4 && argc != 5) { std::fprintf(stderr, "usage: %s cartpole|mountaincar seed steps [max_episode_steps]\n", argv[0]); return 2; }
+    if (argc != 4 && argc != 5) { std::fprintf(stderr, "usage: %s cartpole|mountaincar|cartpole_narrowed seed steps [max_episode_steps]\n", argv[0]); return 2; }
     const long long seed = std::atoll(argv[2]); const int steps = std::atoi(argv[3]);
     if (argc == 5) {
         const size_t max_steps = (size_t)std::atoll(argv[4]);
+        if (!std::strcmp(argv[1], "cartpole_narrowed")) {   // ... behind an ObservationWrapper2 that returns vector<float>
+            using MO = gym::Monitor<gym::TimeLimit<gym::HipCartPoleEnv>, true>; using FO = wrapped_probe::FloatObs<MO>;
+            return wrapped_probe::run_wrapped<FO>(std::make_unique<FO>(std::make_shared<MO>(gym::TimeLimit<gym::HipCartPoleEnv>::make(std::make_unique<gym::HipCartPoleEnv>(), max_steps))), (uint64_t)seed, steps, 2);
+        }
         if (!std::strcmp(argv[1], "cartpole")) {
             using MO = gym::Monitor<gym::TimeLimit<gym::HipCartPoleEnv>, true>;
             return wrapped_probe::run_wrapped<MO>(std::make_unique<MO>(gym::TimeLimit<gym::HipCartPoleEnv>::make(std::make_unique<gym::HipCartPoleEnv>(), max_steps)), (uint64_t)seed, steps, 2);

@@ -7,8 +7,16 @@
 #include <cstdint>
 #include <cstdio>
 #include <memory>
+#include <vector>
 
 namespace wrapped_probe {
+
+// The stack behind an ObservationWrapper2 (common/wrapper.h:231-275) that narrows the env's double state to float — what
+// TensorAdapter::encode(vector<double>) does on the way into SyncVecEnv's batch (tensor_adapter.cpp:84-87).
+template <class Inner> struct FloatObs : gym::ObservationWrapper2<Inner, std::vector<float>> {
+    explicit FloatObs(std::shared_ptr<Inner> const& e) : gym::ObservationWrapper2<Inner, std::vector<float>>(e->observationSpace(), e) {}
+    std::vector<float> observation(std::vector<double>&& x) const noexcept override { return std::vector<float>(x.begin(), x.end()); }
+};
 
 template <class Wrapped> int run_wrapped(std::unique_ptr<Wrapped> env, uint64_t seed, int steps, unsigned n_act) {
     env->seed(seed);

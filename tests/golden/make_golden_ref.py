@@ -36,6 +36,23 @@ def run_wrappers(rew, done, max_steps, steps, driver=None):
         return np.fromfile(fout, REC)
 
 
+UNROLL = np.dtype([("obs", "<f8"), ("reward", "<f4"), ("done", "u1"), ("obs2", "<f4"), ("reward2", "<f4"), ("done2", "u1")])
+
+
+def run_unroll(rew, done, steps, driver=None):
+    """The scripted env under WrapperUnroll<env, ClipRewardEnv stage, observation stage> and under an ObservationWrapper2 adapter
+    (tests/cpp/wrappers_probe.h run_unroll) -> (rows[steps + 1] (row 0 = reset), inner env's step count, flag word)."""
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in"), os.path.join(d, "out")
+        with open(fin, "wb") as f:
+            f.write(np.array([rew.size, 0, steps, 0], np.int64).tobytes()); f.write(rew.tobytes()); f.write(done.tobytes())
+        subprocess.run([driver or DRIVER, "unroll", fin, fout], check=True, capture_output=True)
+        raw = open(fout, "rb").read()
+    n = (steps + 1) * UNROLL.itemsize
+    t, flags = np.frombuffer(raw[n:], np.int64)
+    return np.frombuffer(raw[:n], UNROLL), int(t), int(flags)
+
+
 def rms_batches(seed, nb, F):
     rng = np.random.default_rng(seed)
     out = []
@@ -107,6 +124,9 @@ def main():
     rec = run_wrappers(rew, done, 13, 4000)
     np.savez_compressed(os.path.join(OUT, "ref_wrappers.npz"), script_seed=11, script_len=997, max_steps=13, steps=4000,
                         **{k: rec[k] for k in REC.names})
+    rew, done = wrapper_script(12, 211)
+    rows, t, flags = run_unroll(rew, done, 1000)
+    np.savez_compressed(os.path.join(OUT, "ref_unroll.npz"), script_seed=12, script_len=211, steps=1000, t=t, flags=flags, **{k: rows[k] for k in UNROLL.names})
     F = 4
     rows = run_rms(rms_batches(5, 30, F), F)
     np.savez_compressed(os.path.join(OUT, "ref_rms.npz"), batch_seed=5, n_batches=30, F=F, rows=rows)

@@ -166,6 +166,45 @@ def test_cpp_wrapper_mirror_vs_live_reference_driver():
         assert a.tobytes() == b.tobytes(), (seed, L, max_steps)
 
 
+def unroll_expected(rew, done, steps):
+    """What the probe's two stacks must produce, from the definitions: ScriptEnv's observation is its step count, the chain
+    clips the reward to its sign (zeros pass, clip_reward.h:23) and maps obs -> 2 obs + 1; the adapter returns float(obs / 2 - 3)."""
+    rows = np.zeros(steps + 1, R.UNROLL)
+    rows["obs"][0], rows["obs2"][0] = 1.0, np.float32(-3.0)
+    for s in range(steps):
+        i = s % rew.size
+        r = rew[i]
+        rows["obs"][s + 1] = 2.0 * (s + 1) + 1
+        rows["reward"][s + 1] = r if r == 0 else np.float32(1.0 if r > 0 else -1.0)
+        rows["obs2"][s + 1] = np.float32(0.5 * (s + 1) - 3.0)
+        rows["reward2"][s + 1] = r
+        rows["done"][s + 1] = rows["done2"][s + 1] = done[i]
+    return rows
+
+
+def test_cpp_wrapper_unroll_and_observation_wrapper2_mirror_equal_the_references(tmp_path):
+    """common/wrapper.h's remaining templates (WrapperUnroll, ObservationWrapper2, lastType / NthType) in gym/wrappers.h, under
+    the probe the reference's own were put through: every row equals the frozen reference output bit for bit, and both equal
+    what the definitions give."""
+    assert os.path.exists(MIRROR_WRAPPERS), "build tests/cpp first"
+    g = np.load(os.path.join(G, "ref_unroll.npz"))
+    rew, done = R.wrapper_script(int(g["script_seed"]), int(g["script_len"]))
+    rows, t, flags = R.run_unroll(rew, done, int(g["steps"]), driver=MIRROR_WRAPPERS)
+    want = unroll_expected(rew, done, int(g["steps"]))
+    assert int(g["done"].sum()) > 30
+    for name in R.UNROLL.names:
+        assert rows[name].tobytes() == np.ascontiguousarray(g[name]).tobytes() == want[name].tobytes(), name
+    assert (t, flags) == (int(g["t"]), int(g["flags"])) == (int(g["steps"]), 4)     # no spaces on a bare scripted env; info() forwarded
+
+
+@pytest.mark.skipif(not HAVE_DRIVER, reason="oracle/_ref not built (needs /root/reference; build container only)")
+def test_cpp_wrapper_unroll_mirror_vs_live_reference_driver():
+    for seed, L, steps in ((5, 17, 300), (6, 400, 900)):
+        rew, done = R.wrapper_script(seed, L)
+        a, b = R.run_unroll(rew, done, steps), R.run_unroll(rew, done, steps, driver=MIRROR_WRAPPERS)
+        assert a[0].tobytes() == b[0].tobytes() == unroll_expected(rew, done, steps).tobytes() and a[1:] == b[1:]
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Spaces, Env::seed and the in-tree drop-in: everything of the reference that compiles here without a stand-in header
 # ---------------------------------------------------------------------------------------------------------------------
@@ -272,20 +311,24 @@ HIP_ENV_DEMO = os.path.join(os.path.dirname(G), "cpp", "bin", "hip_env_demo")
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("templates", ["reference", "mirror"])
-@pytest.mark.parametrize("kind,seed,max_steps", [("cartpole", 3, 500), ("cartpole", 11, 9), ("mountaincar", 0, 200), ("mountaincar", 0, 7)])
+@pytest.mark.parametrize("kind,seed,max_steps", [("cartpole", 3, 500), ("cartpole", 11, 9), ("mountaincar", 0, 200), ("mountaincar", 0, 7), ("cartpole_narrowed", 5, 40)])
 def test_reference_monitor_and_timelimit_templates_over_the_gpu_env(oracle, kind, seed, max_steps, templates):
     """The REFERENCE's own wrapper code (wrappers/monitor.h, time_limit.h, clip_reward.h — compiled from its headers) around the
     single-env face, stepping on the GPU: Monitor<TimeLimit<HipCartPoleEnv>> and configs[2]'s per-env stack
     Monitor<ClipRewardEnv<TimeLimit<HipMountainCarEnv>>>.  Every double of every CartPole observation (MountainCar: <= 1e-14),
     rewards, dones, info["TimeLimit.truncated"] and info["episode"] (r, l) equal the oracle's.  "mirror": the same loop
-    (tests/cpp/wrapped_probe.h) with the stand-alone gym/wrappers.h templates instead (tests/cpp/hip_env_demo)."""
+    (tests/cpp/wrapped_probe.h) with the stand-alone gym/wrappers.h templates instead (tests/cpp/hip_env_demo).
+    "cartpole_narrowed": the CartPole stack behind an ObservationWrapper2 (common/wrapper.h:231-275) that returns vector<float>:
+    every observation equals the oracle's double narrowed to float."""
     from tests.oracle_lib import CARTPOLE, MOUNTAINCAR, F_CLIP_REWARD, F_MONITOR, F_TIME_LIMIT
-    cart = kind == "cartpole"
+    narrowed = kind == "cartpole_narrowed"
+    cart = kind.startswith("cartpole")
+    f64 = (lambda row: [float(np.float32(x)) for x in row]) if narrowed else list
     steps, n_act = (450, 2) if cart else (900, 3)
     if templates == "reference":
         if not os.path.exists(DROPIN):
             pytest.skip("oracle/_ref not built (it is built in the container that mounts the reference and travels with the tree)")
-        cmd = [DROPIN, "wrapped" if cart else "wrapped_mc", str(seed), str(steps), str(max_steps)]
+        cmd = [DROPIN, "wrapped_narrowed" if narrowed else "wrapped" if cart else "wrapped_mc", str(seed), str(steps), str(max_steps)]
     else:
         assert os.path.exists(HIP_ENV_DEMO), "build tests/cpp first"
         cmd = [HIP_ENV_DEMO, kind, str(seed), str(steps), str(max_steps)]
@@ -297,7 +340,7 @@ def test_reference_monitor_and_timelimit_templates_over_the_gpu_env(oracle, kind
     v.set_auto_reset(False)
     _, o64 = v.reset(want64=True)
     k = 0
-    assert lines[k][0] == "wreset" and [float(x) for x in lines[k][1:]] == list(o64[0]); k += 1
+    assert lines[k][0] == "wreset" and [float(x) for x in lines[k][1:]] == f64(o64[0]); k += 1
     episodes = truncations = 0
     for t in range(steps):
         a = ((t * 2654435761 & 0xFFFFFFFF) >> 7) % n_act
@@ -306,7 +349,7 @@ def test_reference_monitor_and_timelimit_templates_over_the_gpu_env(oracle, kind
         assert tag == "wstep" and int(tt) == t and int(aa) == a
         assert float(rew) == o["reward"][0] and int(done) == int(o["done"][0]), t
         if cart:
-            assert [float(x) for x in obs] == list(o["obs64"][0]), t
+            assert [float(x) for x in obs] == f64(o["obs64"][0]), t
         else:
             assert np.abs(np.array([float(x) for x in obs]) - o["obs64"][0]).max() <= 1e-14, t
         assert int(has_ep) == int(o["done"][0]), t
@@ -318,6 +361,6 @@ def test_reference_monitor_and_timelimit_templates_over_the_gpu_env(oracle, kind
                 assert int(tr) == int(o["truncated"][0]), t
                 truncations += int(tr)
             _, r64 = v.reset_index(0)
-            assert lines[k][0] == "wreset" and [float(x) for x in lines[k][1:]] == list(r64); k += 1
+            assert lines[k][0] == "wreset" and [float(x) for x in lines[k][1:]] == f64(r64); k += 1
     assert k == len(lines) and episodes >= 4
     assert truncations > 0 if max_steps < 500 else True
