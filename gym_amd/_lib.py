@@ -121,6 +121,8 @@ SIGNATURES = {
     "gymhip_atari_preprocess_indexed": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gymhip_atari_reset_indexed": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_step_indexed": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "gymhip_atari_push_reset": (C.c_int, [_vp, _vp, _vp]),
+    "gymhip_atari_push": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gymhip_atari_materialize_nhwc": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_set_stack_view": (C.c_int, [_vp, C.c_int]),
     "gymhip_atari_materialize_nchw_f32": (C.c_int, [_vp, _vp, _vp]),

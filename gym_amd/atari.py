@@ -10,6 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
+from .vec_env import VecEnv, VecEnvWrapper
 
 
 class AtariPreprocessor:
@@ -86,6 +87,28 @@ class AtariPreprocessor:
         fn = self.lib.gymhip_atari_step_indexed if indexed else self.lib.gymhip_atari_step
         L.check(fn(self.h, ptr, dp, self._stream()), "gymhip_atari_step")
 
+    def _planes(self, planes: torch.Tensor):
+        if planes.dtype not in (torch.uint8, torch.int8) or planes.numel() != self.n * self.dst_hw[0] * self.dst_hw[1]:
+            raise ValueError(f"planes must be a byte tensor of {self.n} x {self.dst_hw[0]} x {self.dst_hw[1]} elements ([N, H, W, 1])")
+        return planes.to(self.device).contiguous()
+
+    def push_reset(self, planes: torch.Tensor):
+        """VecFrameStack::reset over observations that are ALREADY dst_h x dst_w single-channel images (any inner env's
+        [N, H, W, 1] batch, host or device): zero the stack, the planes become the newest frame (gymhip_atari_push_reset)."""
+        t = self._planes(planes)
+        L.check(self.lib.gymhip_atari_push_reset(self.h, C.c_void_p(t.data_ptr()), self._stream()), "gymhip_atari_push_reset")
+
+    def push(self, planes: torch.Tensor, done: torch.Tensor | None = None):
+        """VecFrameStack::stepWait over such observations: shift by one frame, the planes become the newest."""
+        dp = None
+        if done is not None:
+            done = done.reshape(-1).to(self.device, torch.uint8).contiguous()
+            if done.numel() != self.n:
+                raise ValueError("done must hold n_envs flags")
+            dp = C.c_void_p(done.data_ptr())
+        t = self._planes(planes)
+        L.check(self.lib.gymhip_atari_push(self.h, C.c_void_p(t.data_ptr()), dp, self._stream()), "gymhip_atari_push")
+
     def head(self) -> int:
         ring, head = C.c_void_p(), C.c_int32()
         L.check(self.lib.gymhip_atari_stack_buffer(self.h, C.byref(ring), C.byref(head)), "gymhip_atari_stack_buffer")
@@ -128,6 +151,56 @@ class AtariPreprocessor:
         code = L.OUT_F16 if dtype == torch.float16 else L.OUT_BF16
         L.check(self.lib.gymhip_atari_materialize_nchw_16(self.h, C.c_void_p(out.data_ptr()), code, self._stream()), "gymhip_atari_materialize_nchw_16")
         return out
+
+
+class HipVecFrameStack(VecEnvWrapper):
+    """gym::VecFrameStack<false> (wrappers/vec_env/vec_frame_stack.cpp:10-32 over common/stacked_observation.h:96-130) on its own
+    — and, with norm_and_permute, the pair VecNormAndPermute(VecFrameStack(venv)) (vec_atari.cpp:70-81) as one object — over ANY
+    VecEnv whose observation space is a channels-last single-channel byte image {H, W, 1} (WarpFrame's layout).  The inner batch
+    [N, H, W, 1] may be a host or a device tensor; the stack is the device ring (one plane copy per step), the returned
+    observation a device tensor overwritten by the next step: uint8 [N, H, W, nStack] (view "as_written": int8 with the
+    reference's channel contents), or float32 [N, nStack, H, W] = x / 255.  reward / done / info pass through.  C++ twin:
+    gym/hip_vec_frame_stack.h.  Channels-first spaces, a channelOrder other than "last" and reset(index) are rejected — the
+    reference corrupts memory, always throws, and smears one env's frame over every stack there."""
+
+    def __init__(self, venv: VecEnv, nStack: int = 4, channelOrder: str | None = None, norm_and_permute: bool = False, view: str = "intended",
+                 clear_on_done: bool = False, device: int = 0):
+        from . import spaces as S
+        import numpy as np
+        if channelOrder not in (None, "last"):
+            raise RuntimeError("HipVecFrameStack: only channels-last image spaces are supported")
+        shape = tuple(venv.observationSpace().size())
+        if len(shape) != 3 or shape[2] != 1:
+            raise RuntimeError("HipVecFrameStack: the inner observation space must be a channels-last single-channel image {H, W, 1}")
+        H, W = int(shape[0]), int(shape[1])
+        inner = venv.observationSpace()
+        rng = inner.getRange()[0] if isinstance(inner, S.Box) else S.Range(0, 255)
+        space = S.makeBoxSpace(0.0, 1.0, [nStack, H, W]) if norm_and_permute else S.makeBoxSpace(rng.low, rng.high, [H, W, nStack], dtype=np.uint8)
+        super().__init__(venv, space)
+        self.pp = AtariPreprocessor(venv.nEnvs(), n_stack=nStack, src_hw=(H, W), dst_hw=(H, W), clear_on_done=clear_on_done, device=device)
+        if view != "intended":
+            self.pp.set_stack_view(view)
+        self.norm_and_permute, self.clear_on_done = norm_and_permute, clear_on_done
+        self._out = None
+
+    @staticmethod
+    def make(venv, nStack=4, channelOrder=None, **kw):   # vec_frame_stack.cpp:50-54
+        return HipVecFrameStack(venv, nStack, channelOrder, **kw)
+
+    def _observation(self):
+        self._out = self.pp.stacked_nchw_f32(self._out) if self.norm_and_permute else self.pp.stacked_nhwc(self._out)
+        return self._out
+
+    def reset(self, index=None):
+        if index is not None:
+            raise RuntimeError("HipVecFrameStack: reset(index) is not supported (the stack advances for all envs together)")
+        self.pp.push_reset(self.venv.reset())
+        return self._observation()
+
+    def stepWait(self):
+        r = self.venv.stepWait()
+        self.pp.push(r.observation, r.done if self.clear_on_done else None)
+        return r._replace(observation=self._observation())
 
 
 def host_env_post_step(reward, done, lives, state: dict, clip_reward: bool = True):

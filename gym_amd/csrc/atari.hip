@@ -257,6 +257,25 @@ __global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preproc
     }
 }
 
+// VecFrameStack on its own: planes that are ALREADY dst_h x dst_w gray images go into ring slot `slot` (one workgroup per env
+// plane, 4-B units: dst_w % 4 == 0), with the same optional clear of a finished env's older planes as the fused kernel.
+__global__ __launch_bounds__(kBlock) void push_planes_kernel(const uint32_t* __restrict__ planes, uint8_t* ring, int64_t n, int plane4, int k, int slot,
+                                                             const uint8_t* done, int clear_on_done) {
+    for (int64_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const uint32_t* src = planes + e * plane4;
+        uint32_t* env0 = (uint32_t*)ring + e * k * (int64_t)plane4;
+        uint32_t* dst = env0 + (int64_t)slot * plane4;
+        for (int i = threadIdx.x; i < plane4; i += kBlock) dst[i] = __builtin_nontemporal_load(src + i);
+        if (clear_on_done && done && done[e]) {
+            for (int s = 0; s < k; s++) {
+                if (s == slot) continue;
+                uint32_t* pl = env0 + (int64_t)s * plane4;
+                for (int i = threadIdx.x; i < plane4; i += kBlock) pl[i] = 0u;
+            }
+        }
+    }
+}
+
 // ring u8 [N][k][P] (slot `head` newest) -> NHWC u8 [N][P][k], channel c = (head + 1 + c) % k (oldest first).
 __global__ __launch_bounds__(kBlock) void materialize_nhwc_kernel(const uint8_t* ring, uint8_t* out, int64_t n, int P, int k, int head) {
     const int64_t total = n * (int64_t)P;
@@ -609,6 +628,31 @@ int gymhip_atari_step(gymhip_atari* h, const uint8_t* frames, const uint8_t* don
 int gymhip_atari_preprocess_indexed(gymhip_atari* h, const uint8_t* screens, uint8_t* out, void* stream) { return preprocess_any(h, true, screens, out, stream); }
 int gymhip_atari_reset_indexed(gymhip_atari* h, const uint8_t* screens, void* stream) { return reset_any(h, true, screens, stream); }
 int gymhip_atari_step_indexed(gymhip_atari* h, const uint8_t* screens, const uint8_t* done, void* stream) { return step_any(h, true, screens, done, stream); }
+
+static int push_any(gymhip_atari* h, const uint8_t* planes, const uint8_t* done, bool reset, void* stream) {
+    if (int rc = check_atari(h)) return rc;
+    if (!planes) return fail(GYMHIP_EINVAL, "planes is null");
+    if ((uintptr_t)planes % 4) return fail(GYMHIP_EINVAL, "planes must be 4-byte aligned");
+    if (!reset && !h->did_reset) return fail(GYMHIP_ESTATE, "atari push before reset");
+    const int64_t plane = (int64_t)h->cfg.dst_h * h->cfg.dst_w;
+    hipStream_t s = (hipStream_t)stream;
+    if (reset) {
+        HIP_TRY(hipMemsetAsync(h->ring, 0, (size_t)h->cfg.n_envs * h->cfg.n_stack * plane, s));   // stacked_observation.h:107
+        h->head = h->cfg.n_stack - 1;
+        h->did_reset = true;
+        h->updates_since_reset = 0;
+    } else {
+        h->updates_since_reset++;
+        h->head = (h->head + 1) % h->cfg.n_stack;
+    }
+    const unsigned grid = (unsigned)std::min<int64_t>(h->cfg.n_envs, 1 << 16);
+    hipLaunchKernelGGL(push_planes_kernel, dim3(grid), dim3(kBlock), 0, s, (const uint32_t*)planes, h->ring, (int64_t)h->cfg.n_envs, (int)(plane / 4),
+                       h->cfg.n_stack, h->head, reset ? nullptr : done, h->cfg.clear_on_done);
+    HIP_TRY(hipGetLastError());
+    return GYMHIP_OK;
+}
+int gymhip_atari_push_reset(gymhip_atari* h, const uint8_t* planes, void* stream) { return push_any(h, planes, nullptr, true, stream); }
+int gymhip_atari_push(gymhip_atari* h, const uint8_t* planes, const uint8_t* done, void* stream) { return push_any(h, planes, done, false, stream); }
 
 int gymhip_atari_set_stack_view(gymhip_atari* h, int view) {
     if (int rc = check_atari(h)) return rc;

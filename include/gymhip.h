@@ -261,6 +261,13 @@ int gymhip_atari_set_palette(gymhip_atari* h, const uint32_t* zrgb256);
 int gymhip_atari_preprocess_indexed(gymhip_atari* h, const uint8_t* screens, uint8_t* out, void* stream);
 int gymhip_atari_reset_indexed(gymhip_atari* h, const uint8_t* screens, void* stream);
 int gymhip_atari_step_indexed(gymhip_atari* h, const uint8_t* screens, const uint8_t* done, void* stream);
+/* VecFrameStack ON ITS OWN (vec_frame_stack.cpp:10-32 over stacked_observation.h:106-130), for an inner VecEnv whose
+ * observations are already dst_h x dst_w single-channel uint8 images (its [N, H, W, 1] batch, on the device, 4-byte aligned):
+ *   _push_reset: VecFrameStack::reset — zero the stack, the planes become the newest frame;
+ *   _push:       VecFrameStack::stepWait — shift by one frame, the planes become the newest (`done` as in _step).
+ * The ring, the views and the materialise calls are those of _reset / _step: only the source of the newest plane differs. */
+int gymhip_atari_push_reset(gymhip_atari* h, const uint8_t* planes, void* stream);
+int gymhip_atari_push(gymhip_atari* h, const uint8_t* planes, const uint8_t* done, void* stream);
 /* The stacked observation as a contiguous tensor: channels-last u8 [n_envs][dst_h][dst_w][n_stack], oldest frame in
  * channel 0 (what VecFrameStack returns over WarpFrame's {84,84,1} space, stacked_observation.h:96-99,203-209). */
 int gymhip_atari_materialize_nhwc(gymhip_atari* h, uint8_t* out, void* stream);

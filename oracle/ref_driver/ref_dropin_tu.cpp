@@ -14,6 +14,7 @@
 
 #include "gym/hip_vec_env.h"
 #include "gym/hip_env.h"
+#include "gym/hip_vec_frame_stack.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +34,8 @@ using WrappedSingle = gym::Monitor<gym::TimeLimit<gym::HipCartPoleEnv>, true>;
 
 // a wrapper written against the reference's VecEnvWrapper, as its own VecNormalize / VecFrameStack are (vec_env_wrapper.h:12-55)
 static_assert(std::is_base_of_v<gym::VecEnvWrapper<false>, gym::HipTrainingVecNormRO>, "the normaliser wrapper class derives from the reference's VecEnvWrapper<false>, as VecNormalize does (vec_normalize.h:21)");
+static_assert(std::is_base_of_v<gym::VecEnvWrapper<false>, gym::HipVecFrameStack> && !std::is_abstract_v<gym::HipVecFrameStack>,
+              "the frame-stack wrapper derives from the reference's VecEnvWrapper<false>, as VecFrameStack does (vec_frame_stack.h:16)");
 struct CountingWrapper : gym::VecEnvWrapper<false> {
     using gym::VecEnvWrapper<false>::VecEnvWrapper;
     int steps = 0;

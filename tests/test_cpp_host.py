@@ -231,3 +231,53 @@ def test_single_env_face_matches_the_oracle_env_bit_for_bit(oracle, env, seed):
             assert lines[k][0] == "reset" and [float(x) for x in lines[k][1:]] == list(r64); k += 1
     assert lines[k] == ["episodes", str(episodes)] and episodes >= (5 if cart else 0)
     assert "already returned done = True" in r.stderr or episodes < 2     # the misuse path printed the reference's warning
+
+
+FS_BIN = os.path.join(ROOT, "tests", "cpp", "bin", "hip_vec_frame_stack_demo")
+
+
+def _scripted_image(n, H, W, t):
+    """tests/cpp/hip_vec_frame_stack_demo.cpp ScriptedImageVecEnv::frame, in numpy (uint32 arithmetic)."""
+    e = (np.arange(n, dtype=np.uint64)[:, None] * 2654435761) & 0xFFFFFFFF
+    q = (np.arange(H * W, dtype=np.uint64)[None, :] * 2246822519) & 0xFFFFFFFF
+    v = e ^ np.uint64((t * 40503) & 0xFFFFFFFF) ^ q
+    v ^= v >> np.uint64(15); v = (v * np.uint64(2246822519)) & np.uint64(0xFFFFFFFF); v ^= v >> np.uint64(13)
+    return ((v >> np.uint64(8)) & np.uint64(0xFF)).astype(np.uint8).reshape(n, H, W)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,where", [("plain", "host"), ("plain", "device"), ("as_written", "host"), ("norm", "device"), ("norm_as_written", "host"), ("clear", "host")])
+def test_hip_vec_frame_stack_cpp_wraps_any_vec_env(oracle, tmp_path, mode, where):
+    """gym::HipVecFrameStack : VecEnvWrapper<false> (gym/hip_vec_frame_stack.h) held as unique_ptr<VecEnv<false>> over a scripted
+    VecEnv<false> of {H, W, 1} byte images: the reference's VecFrameStack, and VecNormAndPermute(VecFrameStack(.)), as wrappers of
+    their own — observation space, every observation against the oracle's frame stack (both views), reward / done untouched."""
+    assert os.path.exists(FS_BIN), "build tests/cpp first"
+    n, H, W, k, steps = 3, 16, 12, 4, 11
+    out = tmp_path / "fs.bin"
+    r = subprocess.run([FS_BIN, mode, str(n), str(H), str(W), str(k), str(steps), where, str(out)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    lines = r.stdout.strip().splitlines()
+    norm, aw = mode.startswith("norm"), mode.endswith("as_written")
+    assert lines[0] == (f"space {k} {H} {W} type 6 nEnvs {n}" if norm else f"space {H} {W} {k} type 1 nEnvs {n}")      # c10::kFloat = 6, kChar = 1
+    assert lines[1] == (f"obs dtype Float dims {n} {k} {H} {W} cuda 1" if norm else f"obs dtype {'Char' if aw else 'Byte'} dims {n} {H} {W} {k} cuda 1")
+    assert lines[2] == "reset_index throws"
+    raw = np.fromfile(out, np.uint8)
+    per = n * H * W * k * (4 if norm else 1)
+    obs = raw[:per * (steps + 1)].reshape(steps + 1, per)
+    rd = raw[per * (steps + 1):].view(np.float32).reshape(steps, 2, n)
+    stack = np.zeros((n, H, W, k), np.uint8)
+    for t in range(steps + 1):
+        f = _scripted_image(n, H, W, t)
+        if t == 0:
+            oracle.framestack_reset(stack, f)
+        else:
+            (oracle.framestack_update_as_written if aw else oracle.framestack_update)(stack, f)
+            done = np.array([(t + e) % 5 == 0 for e in range(n)])
+            if mode == "clear":
+                stack[done, :, :, :-1] = 0                                   # SB3's clear: a finished env keeps only its newest frame
+            assert np.array_equal(rd[t - 1, 0], np.arange(n, dtype=np.float32) + t) and np.array_equal(rd[t - 1, 1], done.astype(np.float32))
+        if norm:
+            want = (oracle.norm_permute_as_written if aw else oracle.norm_permute)(stack)
+            assert np.array_equal(obs[t].view(np.float32).reshape(n, k, H, W), want), t
+        else:
+            assert np.array_equal(obs[t].reshape(n, H, W, k), stack), t
