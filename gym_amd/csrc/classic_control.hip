@@ -55,6 +55,9 @@ constexpr int kMaxGrid = 8192;  // upper bound of the grid-stride launch (sizes 
 constexpr int kDefaultGrid = 512;   // 256 CUs x 2 blocks of 512 threads: best for the float-state and MountainCar kernels and for normaliser engines (fewer partial rows to fold); GYMHIP_GRID overrides
 constexpr int kPlainGrid = 2048;    // CartPole lockstep without the normaliser (the 84-B kernel): 1024 .. 4096 measure alike, 1.5 % above 512 (profiles/r02_sweeps.txt)
 constexpr size_t kNtFootprint = (size_t)336 << 20;   // bytes; see gymhip_create
+constexpr size_t kMallBudget = (size_t)240 << 20;    // bytes of the 256 MiB Infinity Cache a residency plan fills (plan_residency)
+enum : int { kKeepCounter = 1, kKeepReward = 2, kKeepDone = 4, kKeepReturns = 8, kKeepNotDone = 11, kKeepAll = 15 };
+constexpr int kPlans[] = {kKeepAll, kKeepNotDone, kKeepCounter, 0};   // the plans the step kernel is compiled for, most bytes kept first
 constexpr int kMaxCols = 16;    // >= 2F+6 for F=4
 
 enum : int { KIND_CARTPOLE = GYMHIP_ENV_CARTPOLE, KIND_MOUNTAINCAR = GYMHIP_ENV_MOUNTAINCAR };
@@ -283,23 +286,27 @@ using i32x2 = int32_t __attribute__((ext_vector_type(2)));
 // NT is a template argument so that the step kernel can pick per launch: non-temporal pays when the engine's footprint is
 // well beyond the Infinity Cache (16.7 M envs: +7 %), and costs when it (nearly) fits (4 M envs: -16 %) — see kNtFootprint.
 constexpr bool kNtDefault = GYMHIP_NT != 0;
-template <bool NT = kNtDefault, typename V> __device__ inline V ld_stream(const V* ptr) {
-    if constexpr (NT) return __builtin_nontemporal_load(ptr);
-    else return *ptr;
+// The cache policy of an access is a COMPILE-TIME property here on purpose.  A run-time choice (`keep ? plain : non-temporal`)
+// does not survive the optimiser: it sees the same load (store) in both arms, sinks them into one access behind a pointer phi
+// and drops the non-temporal hint — measured: every plan then ran like an all-temporal kernel; keeping the arms apart with asm
+// fences costs the float-state kernel 15 %.  So plans are template arguments (step_kernel<.., KEEP>).
+template <bool NT = kNtDefault, typename V> __device__ inline V ld_stream(const V* base, int64_t i) {
+    if constexpr (NT) return __builtin_nontemporal_load(base + i);
+    else return base[i];
 }
-template <bool NT = kNtDefault, typename V> __device__ inline void st_stream(V* ptr, V v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, ptr);
-    else *ptr = v;
+template <bool NT = kNtDefault, typename V> __device__ inline void st_stream(V* base, int64_t i, V v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, base + i);
+    else base[i] = v;
 }
-
-template <bool NT = kNtDefault> __device__ inline void load_obs(const float* obs, int64_t i, float (&s)[4]) { f32x4 v = ld_stream<NT>((const f32x4*)obs + i); s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w; }
-template <bool NT = kNtDefault> __device__ inline void load_obs(const float* obs, int64_t i, float (&s)[2]) { f32x2 v = ld_stream<NT>((const f32x2*)obs + i); s[0] = v.x; s[1] = v.y; }
-template <bool NT = kNtDefault> __device__ inline void store_obs(float* obs, int64_t i, const float (&s)[4]) { f32x4 v = {s[0], s[1], s[2], s[3]}; st_stream<NT>((f32x4*)obs + i, v); }
-template <bool NT = kNtDefault> __device__ inline void store_obs(float* obs, int64_t i, const float (&s)[2]) { f32x2 v = {s[0], s[1]}; st_stream<NT>((f32x2*)obs + i, v); }
-template <bool NT = kNtDefault> __device__ inline void load_i32(const int32_t* a, int64_t i, int32_t (&k)[4]) { i32x4 v = ld_stream<NT>((const i32x4*)a + i); k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w; }
-template <bool NT = kNtDefault> __device__ inline void load_i32(const int32_t* a, int64_t i, int32_t (&k)[2]) { i32x2 v = ld_stream<NT>((const i32x2*)a + i); k[0] = v.x; k[1] = v.y; }
-template <bool NT = kNtDefault> __device__ inline void store_i32(int32_t* a, int64_t i, const int32_t (&k)[4]) { i32x4 v = {k[0], k[1], k[2], k[3]}; st_stream<NT>((i32x4*)a + i, v); }
-template <bool NT = kNtDefault> __device__ inline void store_i32(int32_t* a, int64_t i, const int32_t (&k)[2]) { i32x2 v = {k[0], k[1]}; st_stream<NT>((i32x2*)a + i, v); }
+// Row accessors.  Rows are 16-B (F = 4) or 8-B (F = 2) vectors: one coalesced access per lane.
+template <bool NT = kNtDefault> __device__ inline void load_obs(const float* obs, int64_t i, float (&s)[4]) { f32x4 v = ld_stream<NT>((const f32x4*)obs, i); s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w; }
+template <bool NT = kNtDefault> __device__ inline void load_obs(const float* obs, int64_t i, float (&s)[2]) { f32x2 v = ld_stream<NT>((const f32x2*)obs, i); s[0] = v.x; s[1] = v.y; }
+template <bool NT = kNtDefault> __device__ inline void store_obs(float* obs, int64_t i, const float (&s)[4]) { f32x4 v = {s[0], s[1], s[2], s[3]}; st_stream<NT>((f32x4*)obs, i, v); }
+template <bool NT = kNtDefault> __device__ inline void store_obs(float* obs, int64_t i, const float (&s)[2]) { f32x2 v = {s[0], s[1]}; st_stream<NT>((f32x2*)obs, i, v); }
+template <bool NT = kNtDefault> __device__ inline void load_i32(const int32_t* a, int64_t i, int32_t (&k)[4]) { i32x4 v = ld_stream<NT>((const i32x4*)a, i); k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w; }
+template <bool NT = kNtDefault> __device__ inline void load_i32(const int32_t* a, int64_t i, int32_t (&k)[2]) { i32x2 v = ld_stream<NT>((const i32x2*)a, i); k[0] = v.x; k[1] = v.y; }
+template <bool NT = kNtDefault> __device__ inline void store_i32(int32_t* a, int64_t i, const int32_t (&k)[4]) { i32x4 v = {k[0], k[1], k[2], k[3]}; st_stream<NT>((i32x4*)a, i, v); }
+template <bool NT = kNtDefault> __device__ inline void store_i32(int32_t* a, int64_t i, const int32_t (&k)[2]) { i32x2 v = {k[0], k[1]}; st_stream<NT>((i32x2*)a, i, v); }
 
 // Split-double state (LOCKSTEP).  A double d is kept as the pair (f, k): f = (float)d — exactly the observation the API
 // returns, so the obs row doubles as the high half of the state — and k = (d - (double)f) * 2^(53 - e_f), e_f = f's
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(kFoldThreads) void reduce_partials_kernel(const dou
 // ------------------------------------------------------------------------------------------------------------
 // Kernel A: one VecEnv::step for every env.
 // ------------------------------------------------------------------------------------------------------------
-template <int KIND, bool LOCKSTEP, typename ActT, bool NORM, bool NT>
+template <int KIND, bool LOCKSTEP, typename ActT, bool NORM, bool NT, int KEEP>   // KEEP: the 4-B lanes an NT kernel keeps in the Infinity Cache (one of kPlans)
 #ifndef GYMHIP_STEP_WAVES
 #define GYMHIP_STEP_WAVES 1   // experiment knob: min waves per SIMD the step kernel is compiled for (caps its VGPRs)
 #endif
@@ -493,12 +500,16 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
     };
     // `i` must be a valid env index.  A lane with no next iteration issues no loads (an earlier form re-read the lane's own
     // inputs unconditionally: one wasted 40-B read per THREAD per launch, 5 % of the fetch traffic at 2048 x 512 threads).
+    // Residency plan (NT kernels only; plan_residency): the 4-B lanes in KEEP are accessed with the default (temporal) policy, so
+    // that they stay in the 256 MiB Infinity Cache from one step to the next, while everything else streams past it non-temporally.
+    constexpr bool NT_COUNTER = NT && !(KEEP & kKeepCounter), NT_REWARD = NT && !(KEEP & kKeepReward), NT_DONE = NT && !(KEEP & kKeepDone),
+                   NT_RETURNS = NT && !(KEEP & kKeepReturns);
     auto issue_loads = [&](int64_t i, Inputs& in) {
         load_obs<NT>(b.obs, i, in.o);
         if constexpr (LOCKSTEP) load_i32<NT>((const int32_t*)b.state, i, in.k);
-        in.action = (int)ld_stream<NT>(actions + i);
-        in.w = ld_stream<NT>(b.counter + i);
-        if constexpr (NORM) in.ret = ret_lane ? ld_stream<NT>(b.returns + i) : 0.f;
+        in.action = (int)ld_stream<NT>(actions, i);
+        in.w = ld_stream<NT_COUNTER>(b.counter, i);
+        if constexpr (NORM) in.ret = ret_lane ? ld_stream<NT_RETURNS>(b.returns, i) : 0.f;
     };
 
     // Software pipeline: iteration k+1's loads are issued before iteration k's arithmetic, so they are in flight under
@@ -568,9 +579,9 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
         for (int f = 0; f < F; f++) o[f] = (float)s[f];
         if constexpr (LOCKSTEP) store_state<F, NT>(b, i, s, o, p.error_flag);
         store_obs<NT>(b.obs, i, o);
-        st_stream<NT>(b.counter + i, CounterWord<KIND>::pack(t, cursor, done, trunc));
-        st_stream<NT>(b.reward + i, reward);
-        st_stream<NT>(b.done + i, done ? 1.f : 0.f);
+        st_stream<NT_COUNTER>(b.counter, i, CounterWord<KIND>::pack(t, cursor, done, trunc));
+        st_stream<NT_REWARD>(b.reward, i, reward);
+        st_stream<NT_DONE>(b.done, i, done ? 1.f : 0.f);
 
         if constexpr (NORM) {
 #pragma unroll
@@ -579,7 +590,7 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
                 float r = cur.ret * p.gamma + reward;              // vec_normalize.h:132
                 double d = (double)r - (double)shift[F];
                 acc[2 * F] += d; acc[2 * F + 1] += d * d;
-                st_stream<NT>(b.returns + i, done ? 0.f : r);     // vec_normalize.h:175 (applied after the RMS update)
+                st_stream<NT_RETURNS>(b.returns, i, done ? 0.f : r);   // vec_normalize.h:175 (applied after the RMS update)
             }
         }
 #if GYMHIP_PIPE
@@ -676,7 +687,7 @@ __device__ inline void rms_update(float& mean, float& var, float count, float bm
 // Kernel B: apply the (all-reduced) batch moments to the running statistics, then normalise (vec_normalize.h:118-129).
 // Every block derives the new statistics redundantly (identical instructions on identical inputs); block 0 publishes
 // them into the other ping-pong slot, which only the NEXT launches read.
-template <int F, bool NT>
+template <int F, bool NT, bool KEEP_REWARD = false>   // KEEP_REWARD: an NT kernel leaves the reward lane in the Infinity Cache (plan_residency)
 __global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
     // A thread's unit of streaming work is a GROUP: F 16-B observation vectors (one from each of F equal chunks of the first
     // 4 * ng envs' rows) + one 16-B reward vector; ng = n / 4 groups cover exactly the first 4 * ng envs.  The first
@@ -690,7 +701,9 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
 #pragma unroll
             for (int v = 0; v < F; v++) load_obs<NT>(q.obs, v * ng + j, g.o[v]);   // F chunks of ng vectors: every load instruction is lane-contiguous
         }
-        if (q.norm_reward) load_obs<NT>(q.reward, j, g.r);
+        if (q.norm_reward) {
+            load_obs<NT && !KEEP_REWARD>(q.reward, j, g.r);
+        }
     };
     Group cur;
     if (tid < ng) load_group(tid, cur);
@@ -773,7 +786,7 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
         if (q.norm_reward) {
 #pragma unroll
             for (int c = 0; c < 4; c++) cur.r[c] = norm_r(cur.r[c]);
-            store_obs<NT>(q.reward, j, cur.r);
+            store_obs<NT && !KEEP_REWARD>(q.reward, j, cur.r);
         }
         cur = nxt;
     }
@@ -1106,6 +1119,7 @@ struct gymhip_engine {
     bool pending_finish;     // a *_begin with the normaliser on awaits its *_finish
     bool pending_is_reset;
     bool stream_nt;          // step kernel streams with non-temporal accesses (footprint beyond the Infinity Cache)
+    int keep_small;          // residency plan of an NT engine (plan_residency): the 4-B lanes that stay in the Infinity Cache, one of kPlans
     double* scratch_dev;     // this device's copy of the static `scratch` array (resolve_scratch)
 
     template <typename T> T* at(size_t off) const { return off == (size_t)-1 ? nullptr : (T*)(ws + off); }
@@ -1113,6 +1127,33 @@ struct gymhip_engine {
 };
 
 namespace {
+
+// The residency plan of an engine that streams non-temporally (its per-step footprint does not fit the 256 MiB Infinity Cache).
+// Non-temporal accesses pass that cache by; what is accessed with the default policy stays in it from one step to the next.
+// So the 4-B lanes (counter, reward, done, returns) are kept there when they fit kMallBudget and only the wide rows and the
+// actions stream from HBM.  Measured at 16.7 M CartPole envs, lockstep (profiles/r02_sweeps.txt): counter alone +9 % for 64 MiB,
+// reward + done +10 % for 128 MiB, all three 0.685 -> 0.82 of 8 TB/s; kept bytes beyond ~256 MiB lose everything again (a kept
+// prefix of the wide rows on top of 192 MiB of lanes: +2 % at 256 MiB in total, -3 % at 272 MiB).  The step kernel is compiled
+// for the plans in kPlans; the first one that fits is taken.  GYMHIP_MALL_MB / GYMHIP_KEEP_SMALL override for sweeps.
+void plan_residency(gymhip_engine* h) {
+    h->keep_small = 0;
+    if (h->stream_nt) {
+        size_t budget = kMallBudget;
+        if (const char* e = getenv("GYMHIP_MALL_MB")) budget = (size_t)std::max(0, atoi(e)) << 20;
+        const bool returns = h->L.returns != (size_t)-1;
+        const bool tape = h->cfg.env_kind == KIND_CARTPOLE && h->cfg.reset_mode == GYMHIP_RESET_TAPE;
+        for (int plan : kPlans) {
+            if (tape && plan == kKeepAll) continue;   // measured: with the reset-tape gather in the mix the done lane is better streamed (0.707 vs 0.677 lockstep, 0.650 vs 0.635 float)
+            int lanes = 0;
+            for (int bit : {kKeepCounter, kKeepReward, kKeepDone, kKeepReturns}) lanes += (plan & bit) && (bit != kKeepReturns || returns);
+            if ((size_t)h->cfg.n_envs * 4 * lanes <= budget) { h->keep_small = plan; break; }
+        }
+    }
+    if (const char* e = getenv("GYMHIP_KEEP_SMALL")) {
+        const int v = atoi(e);
+        for (int plan : kPlans) if (plan == v) h->keep_small = v;
+    }
+}
 
 StepParams make_params(gymhip_engine* h) {
     StepParams p{};
@@ -1174,18 +1215,23 @@ int resolve_scratch(int device, double** out) {
     return GYMHIP_OK;
 }
 
-template <int KIND, bool LOCKSTEP, bool NORM, bool NT>
+template <int KIND, bool LOCKSTEP, bool NORM, bool NT, int KEEP>
 void launch_step_act(gymhip_engine* h, const StepParams& p, int action_dtype, hipStream_t s) {
     switch (action_dtype) {
-        case GYMHIP_ACT_I32: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, int32_t, NORM, NT>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
-        case GYMHIP_ACT_I64: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, int64_t, NORM, NT>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
-        default: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, uint8_t, NORM, NT>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
+        case GYMHIP_ACT_I32: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, int32_t, NORM, NT, KEEP>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
+        case GYMHIP_ACT_I64: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, int64_t, NORM, NT, KEEP>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
+        default: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, uint8_t, NORM, NT, KEEP>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
     }
 }
 template <int KIND, bool LOCKSTEP, bool NORM>
 void launch_step_nt(gymhip_engine* h, const StepParams& p, int action_dtype, hipStream_t s) {
-    if (h->stream_nt) launch_step_act<KIND, LOCKSTEP, NORM, true>(h, p, action_dtype, s);
-    else launch_step_act<KIND, LOCKSTEP, NORM, false>(h, p, action_dtype, s);
+    if (!h->stream_nt) { launch_step_act<KIND, LOCKSTEP, NORM, false, kKeepAll>(h, p, action_dtype, s); return; }
+    switch (h->keep_small) {   // one of kPlans (plan_residency)
+        case kKeepAll: launch_step_act<KIND, LOCKSTEP, NORM, true, kKeepAll>(h, p, action_dtype, s); break;
+        case kKeepNotDone: launch_step_act<KIND, LOCKSTEP, NORM, true, kKeepNotDone>(h, p, action_dtype, s); break;
+        case kKeepCounter: launch_step_act<KIND, LOCKSTEP, NORM, true, kKeepCounter>(h, p, action_dtype, s); break;
+        default: launch_step_act<KIND, LOCKSTEP, NORM, true, 0>(h, p, action_dtype, s); break;
+    }
 }
 template <int KIND, bool LOCKSTEP>
 void launch_step_norm(gymhip_engine* h, const StepParams& p, int action_dtype, hipStream_t s) {
@@ -1232,12 +1278,15 @@ int launch_normalize(gymhip_engine* h, bool is_reset, hipStream_t s, bool fold) 
     q.norm_reward = !is_reset && (w & GYMHIP_WRAP_NORM_REWARD);
     q.update_obs = training && (w & GYMHIP_WRAP_NORM_OBS);                       // vec_normalize.h:149-151,162-164
     q.update_ret = !is_reset && training && (w & GYMHIP_WRAP_NORM_REWARD);       // vec_normalize.h:169-170
+    const bool keep_reward = h->keep_small & kKeepReward;
     if (h->F == 4) {
-        if (h->stream_nt) hipLaunchKernelGGL((normalize_kernel<4, true>), dim3(h->grid), dim3(kBlock), 0, s, q);
-        else hipLaunchKernelGGL((normalize_kernel<4, false>), dim3(h->grid), dim3(kBlock), 0, s, q);
+        if (!h->stream_nt) hipLaunchKernelGGL((normalize_kernel<4, false>), dim3(h->grid), dim3(kBlock), 0, s, q);
+        else if (keep_reward) hipLaunchKernelGGL((normalize_kernel<4, true, true>), dim3(h->grid), dim3(kBlock), 0, s, q);
+        else hipLaunchKernelGGL((normalize_kernel<4, true>), dim3(h->grid), dim3(kBlock), 0, s, q);
     } else {
-        if (h->stream_nt) hipLaunchKernelGGL((normalize_kernel<2, true>), dim3(h->grid), dim3(kBlock), 0, s, q);
-        else hipLaunchKernelGGL((normalize_kernel<2, false>), dim3(h->grid), dim3(kBlock), 0, s, q);
+        if (!h->stream_nt) hipLaunchKernelGGL((normalize_kernel<2, false>), dim3(h->grid), dim3(kBlock), 0, s, q);
+        else if (keep_reward) hipLaunchKernelGGL((normalize_kernel<2, true, true>), dim3(h->grid), dim3(kBlock), 0, s, q);
+        else hipLaunchKernelGGL((normalize_kernel<2, true>), dim3(h->grid), dim3(kBlock), 0, s, q);
     }
     return GYMHIP_OK;   // the kernel always publishes the (possibly unchanged) statistics into the other slot and bumps the device-side tick
 }
@@ -1274,7 +1323,10 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
     h->did_reset = false; h->pending_finish = false; h->pending_is_reset = false;
     // Non-temporal streaming pays only once the per-step footprint (workspace + an int32 action row) no longer fits the
     // 256 MiB Infinity Cache; measured crossover on MI355X between 302 MB (temporal +14 %) and 403 MB (non-temporal +6 %).
-    h->stream_nt = kNtDefault && h->L.total + (size_t)cfg->n_envs * 4 > kNtFootprint;
+    size_t nt_footprint = kNtFootprint;
+    if (const char* e = getenv("GYMHIP_NT_MB")) nt_footprint = (size_t)std::max(0, atoi(e)) << 20;   // sweeps only
+    h->stream_nt = kNtDefault && h->L.total + (size_t)cfg->n_envs * 4 > nt_footprint;
+    plan_residency(h);
     if (int rc = resolve_scratch(device, &h->scratch_dev)) { delete h; return rc; }
     if (workspace) {
         if (workspace_bytes < h->L.total || ((uintptr_t)workspace & 255)) { delete h; return fail(GYMHIP_EINVAL, "workspace too small (%zu < %zu) or not 256-B aligned", workspace_bytes, h->L.total); }
