@@ -34,6 +34,7 @@ using namespace gymhip;
 namespace {
 
 constexpr int kBlock = 256;     // elementwise helper kernels
+constexpr size_t kRingKeepBytes = (size_t)240 << 20;   // a ring up to this size is read with the default cache policy (see materialize_nchw_kernel)
 constexpr int kFrameBlock = 512;  // one workgroup per frame: 8 waves; 4 workgroups (37 KB LDS each) fill a CU's 32 wave slots
 #ifndef GYMHIP_ATARI_WAVES
 #define GYMHIP_ATARI_WAVES 6   // min waves/SIMD: 80 VGPRs -> 3 frames (24 waves) per CU; 4 = 4.67 TB/s, 6 = 5.14, 8 spills = 3.5 (profiles/r01_sweep.txt)
@@ -339,7 +340,12 @@ constexpr int kViewIntended = -2;   // `first` argument of the materialise kerne
 #define GYMHIP_MAT_UNR 4       // items whose loads are issued before the first of them is converted and stored
 #endif
 constexpr int kMatBlock = GYMHIP_MAT_BLOCK;
-template <int MODE, int BF16, int AW>
+// RING_NT: how the ring is read.  A ring that fits the 256 MiB Infinity Cache (4096 envs: 116 MB) is read with the default policy:
+// the planes then stay in that cache from one step to the next — three of the four planes a step reads were read by the step
+// before, the fourth was just written by the preprocess kernel — while the (4 - 8 x larger, write-once) output streams past it
+// non-temporally.  Measured at 4096 envs: f32 0.105 -> 0.095 ms (0.69 -> 0.76 of 8 TB/s), bf16 0.070 -> 0.065; inside the
+// step pipeline (preprocess, then this) f32 0.114 -> 0.103.  Larger rings are streamed non-temporally as before.
+template <int MODE, int BF16, int AW, bool RING_NT>
 __global__ __launch_bounds__(kMatBlock) void materialize_nchw_kernel(const uint8_t* __restrict__ ring, void* __restrict__ out, int64_t planes, int P, int k, int head, int split,
                                                                     int first) {
     // AW = 0: the intended shift view (`first` unused).  AW = 1: the as-written view — channel 0 = ring slot `first` (zeros if < 0),
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(kMatBlock) void materialize_nchw_kernel(const uint8
         for (int q0 = lo + (int)threadIdx.x; q0 < hi; q0 += kMatBlock * UNR) {
             InV v[UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; u++) { const int q = q0 + u * kMatBlock; if (q < hi) v[u] = zero ? InV{} : __builtin_nontemporal_load(src + q); }
+            for (int u = 0; u < UNR; u++) { const int q = q0 + u * kMatBlock; if (q < hi) v[u] = zero ? InV{} : (RING_NT ? __builtin_nontemporal_load(src + q) : src[q]); }
 #pragma unroll
             for (int u = 0; u < UNR; u++) {
                 const int q = q0 + u * kMatBlock;
@@ -490,7 +496,7 @@ void materialize_shape(int64_t planes, int items, int* split, unsigned* grid) {
 
 // One launch of the NCHW materialisation: MODE / BF16 pick the pixel format, the handle's view picks AW.  As written, the stack
 // straight after reset() equals the intended one in channel CONTENT, but its bytes are still read as int8.
-template <int MODE, int BF16> int launch_nchw(gymhip_atari* h, void* out, int px_per_item, hipStream_t s) {
+template <int MODE, int BF16, bool RING_NT> int launch_nchw_policy(gymhip_atari* h, void* out, int px_per_item, hipStream_t s) {
     const int P = h->cfg.dst_h * h->cfg.dst_w, k = h->cfg.n_stack;
     const int64_t planes = h->cfg.n_envs * k;
     int split; unsigned grid;
@@ -498,13 +504,17 @@ template <int MODE, int BF16> int launch_nchw(gymhip_atari* h, void* out, int px
     if (h->view == GYMHIP_STACK_AS_WRITTEN) {
         // straight after reset() the stack is [0, .., 0, f] in both views: the intended mapping, with the signed reading (AW = 2)
         const int first = view_first(h);
-        if (first == kViewIntended) hipLaunchKernelGGL((materialize_nchw_kernel<MODE, BF16, 2>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, h->head, split, 0);
-        else hipLaunchKernelGGL((materialize_nchw_kernel<MODE, BF16, 1>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, h->head, split, first);
+        if (first == kViewIntended) hipLaunchKernelGGL((materialize_nchw_kernel<MODE, BF16, 2, RING_NT>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, h->head, split, 0);
+        else hipLaunchKernelGGL((materialize_nchw_kernel<MODE, BF16, 1, RING_NT>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, h->head, split, first);
     } else {
-        hipLaunchKernelGGL((materialize_nchw_kernel<MODE, BF16, 0>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, h->head, split, 0);
+        hipLaunchKernelGGL((materialize_nchw_kernel<MODE, BF16, 0, RING_NT>), dim3(grid), dim3(kMatBlock), 0, s, h->ring, out, planes, P, k, h->head, split, 0);
     }
     HIP_TRY(hipGetLastError());
     return GYMHIP_OK;
+}
+template <int MODE, int BF16> int launch_nchw(gymhip_atari* h, void* out, int px_per_item, hipStream_t s) {
+    const size_t ring_bytes = (size_t)h->cfg.n_envs * h->cfg.n_stack * h->cfg.dst_h * h->cfg.dst_w;
+    return ring_bytes <= kRingKeepBytes ? launch_nchw_policy<MODE, BF16, false>(h, out, px_per_item, s) : launch_nchw_policy<MODE, BF16, true>(h, out, px_per_item, s);
 }
 }  // namespace
 
