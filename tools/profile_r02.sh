@@ -7,9 +7,11 @@ R=$PWD
 timeout -k 10 500 python -u bench.py > gpurun_out/r02_bench_1gpu.json 2> gpurun_out/bench_r02.err || exit 1
 timeout -k 10 200 python -u bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline > gpurun_out/r02_bench_driver_style.json 2>> gpurun_out/bench_r02.err || exit 1
 cd /tmp
+# kernel trace of the default bench command's headline leg in steady state (the pre-warm's launches are part of the trace: same kernel, same state)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -- python3 $R/bench.py --no-cpu-baseline --no-extra > $R/gpurun_out/prof_trace.log 2>&1 || exit 1
+# PMC passes: no pre-warm, so that the first profiled dispatches are the first steps after the reset (no env done yet: known bytes, used as calibration)
 export GYM_BENCH_PREWARM_S=0
 B="python3 $R/bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-extra"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -- $B > $R/gpurun_out/prof_trace.log 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- $B > $R/gpurun_out/prof_fetch.log 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- $B > $R/gpurun_out/prof_write.log 2>&1 || exit 1
 BT="$B --reset-mode tape"
