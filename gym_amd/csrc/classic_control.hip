@@ -309,26 +309,25 @@ template <bool NT = kNtDefault> __device__ inline void store_i32(int32_t* a, int
 template <bool NT = kNtDefault> __device__ inline void store_i32(int32_t* a, int64_t i, const int32_t (&k)[2]) { i32x2 v = {k[0], k[1]}; st_stream<NT>((i32x2*)a, i, v); }
 
 // Split-double state (LOCKSTEP).  A double d is kept as the pair (f, k): f = (float)d — exactly the observation the API
-// returns, so the obs row doubles as the high half of the state — and k = (d - (double)f) * 2^(53 - e_f), e_f = f's
-// unbiased exponent.  d - f is exact (|d - f| <= ulp_f/2 = 2^(e_f-24)) and a multiple of 2^(e_f-53) (d has 53 significant
-// bits and exponent e_f or e_f - 1), so k is an integer with |k| <= 2^29, and d == (double)f + k * 2^(e_f-53) exactly.
+// returns, so the obs row doubles as the high half of the state — and k = bits(d) - bits((double)f), the distance between the
+// two IEEE-754 bit patterns as a signed integer (= the number of doubles between them: patterns of one sign are ordered like
+// their magnitudes, across binades too).  |d - (double)f| <= ulp_f / 2 = 2^(e_f - 24) and the doubles there are at least
+// 2^(e_f - 53) apart (d has exponent e_f or e_f - 1), so |k| <= 2^29: an int32, and d == from_bits(bits((double)f) + k) exactly.
 // 8 B per state element become 4 B beyond the obs row that is written anyway.  Not representable: nonzero |d| < 2^-126
 // and non-finite d; the dynamics cannot produce either (every value is a short sum of terms >= 2^-80 in magnitude),
 // and bit 2 of the error flag reports it if it ever happens.
-// Both are branch-free (selects): they run four times per env-step on the hot path.
+// Integer arithmetic on purpose: two conversions, a 32-bit subtract and a 64-bit add per element, where the first form of this
+// format (k = (d - f) scaled by a power of two) spent a double multiply, a double add / subtract and two int <-> double
+// conversions on each side — they run four times per env-step on the hot path, and fp64 issues at half rate.
 __device__ inline int32_t split_residual(double d, float f, bool& out_of_range) {
-    const int e = (int)((__float_as_uint(f) >> 23) & 0xffu);
+    const uint32_t e = (__float_as_uint(f) >> 23) & 0xffu;
     const bool bad = e == 0 || e == 255;                     // f is zero/subnormal or non-finite: no residual
     out_of_range |= bad && d != 0.0;
-    const double scale = __longlong_as_double((long long)(1023 + 180 - e) << 52);   // 2^(53 - (e - 127)), finite for any e
-    const int32_t k = (int32_t)((d - (double)f) * scale);
+    const int32_t k = (int32_t)(__double_as_longlong(d) - __double_as_longlong((double)f));
     return bad ? 0 : k;
 }
-__device__ inline double split_join(float f, int32_t k) {
-    const int e = (int)((__float_as_uint(f) >> 23) & 0xffu);
-    const double inv = __longlong_as_double((long long)(1023 - 180 + e) << 52);     // 2^((e - 127) - 53), finite for any e
-    const double hi = (double)f;
-    return k == 0 ? hi : hi + (double)k * inv;               // k == 0 keeps -0.0 and the e = 0 / 255 cases untouched
+__device__ inline double split_join(float f, int32_t k) {   // k == 0 (also every e = 0 / 255 case) returns (double)f itself, -0.0 included
+    return __longlong_as_double(__double_as_longlong((double)f) + (long long)k);
 }
 template <int F> __device__ inline void join_state(const float (&o)[F], const int32_t (&k)[F], double (&s)[F]) {
 #pragma unroll

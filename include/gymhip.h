@@ -70,9 +70,9 @@ typedef struct gymhip_buffers {
     int32_t obs_dim;
     int32_t moments_len;            /* doubles in `moments` */
     void* state;                    /* LOCKSTEP: i32 [N][F] residuals k of the split-double state — the reference's double
-                                       m_State element (cartpole.h:41, mountain_car.h:52) is exactly
-                                       (double)obs + k * 2^(e-53), e = obs' unbiased exponent; gymhip_read_state_f64()
-                                       joins the halves.  F32: same memory as obs */
+                                       m_State element (cartpole.h:41, mountain_car.h:52) is exactly the
+                                       double whose IEEE-754 bit pattern is bits((double)obs) + k, |k| <= 2^29;
+                                       gymhip_read_state_f64() joins the halves.  F32: same memory as obs */
     float* obs;                     /* f32 [N][F] raw observation after auto-reset (VecNormalize::oldObs).  It is also the
                                        high half of the state: read-only for callers */
     float* obs_norm;                /* f32 [N][F] normalised observation (NORM_OBS) */

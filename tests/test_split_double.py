@@ -11,19 +11,14 @@ def split(d):
     f = d.astype(np.float32)
     e = ((f.view(np.uint32) >> 23) & 0xFF).astype(np.int64)
     ok = (e != 0) & (e != 255)
-    scale = np.ldexp(1.0, np.where(ok, 180 - e, 0).astype(np.int32))
-    kf = (d - f.astype(np.float64)) * scale
-    kf = np.where(ok, kf, 0.0)
-    assert np.array_equal(kf, np.rint(kf)), "residual is not an integer"
-    assert np.abs(kf).max() <= 2.0 ** 29
-    return f, kf.astype(np.int32), ok
+    k = d.view(np.int64) - f.astype(np.float64).view(np.int64)       # distance between the two bit patterns
+    k = np.where(ok, k, 0)
+    assert np.abs(k).max() <= 2 ** 29
+    return f, k.astype(np.int32), ok
 
 
 def join(f, k):
-    e = ((f.view(np.uint32) >> 23) & 0xFF).astype(np.int64)
-    ok = (e != 0) & (e != 255)
-    inv = np.ldexp(1.0, np.where(ok, e - 180, 0).astype(np.int32))
-    return np.where(ok, f.astype(np.float64) + k.astype(np.float64) * inv, f.astype(np.float64))
+    return (f.astype(np.float64).view(np.int64) + k.astype(np.int64)).view(np.float64)
 
 
 def roundtrip(d):
