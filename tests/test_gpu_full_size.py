@@ -163,3 +163,44 @@ def test_cartpole_268m_envs_index_arithmetic_beyond_4_gib():
     running = float(big.counters()["elapsed"].sum(dtype=torch.float64))
     assert running + len_total == float(n_big) * T
     assert done_total >= 2.0 * n_big                       # TimeLimit(13) over 30 steps: at least two finished episodes per env
+
+
+@pytest.mark.parametrize("kind,precision,norm", [("cartpole", "lockstep", False), ("cartpole", "f32", False), ("mountaincar", "lockstep", True)])
+def test_every_residency_plan_computes_the_same_bits(monkeypatch, kind, precision, norm):
+    """The cache policy of an engine that streams non-temporally is a template argument of its step kernel (plan_residency: all
+    4-byte lanes kept in the Infinity Cache / all but done / counter / none), i.e. four instantiations per kernel; the plan
+    changes speed only.  12.6 M envs (past the non-temporal threshold for every variant here), 40 steps, each plan forced through
+    GYMHIP_KEEP_SMALL: observations, rewards, dones, counter words, the exact state and the running statistics are bit-identical."""
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+    n, T = 12 * 1024 * 1024, 40
+    cart = kind == "cartpole"
+    w = L.WRAP_TIME_LIMIT | L.WRAP_MONITOR | ((L.WRAP_CLIP_REWARD | L.WRAP_NORM_OBS | L.WRAP_NORM_REWARD | L.WRAP_NORM_TRAINING) if norm else 0)
+    acts = [_actions(n, t, 2 if cart else 3) for t in range(4)]
+    want = None
+    for plan in ("0", "1", "11", "15", None):
+        if plan is None:
+            monkeypatch.delenv("GYMHIP_KEEP_SMALL", raising=False)     # the planner's own choice
+        else:
+            monkeypatch.setenv("GYMHIP_KEEP_SMALL", plan)
+        eng = Engine(EngineConfig(env_kind=L.ENV_CARTPOLE if cart else L.ENV_MOUNTAINCAR, n_envs=n,
+                                  precision=L.PRECISION_LOCKSTEP_F64 if precision == "lockstep" else L.PRECISION_F32, reset_mode=L.RESET_COUNTER_RNG,
+                                  wrappers=w, max_episode_steps=9 if cart else 13, seed=3, clip_obs=10.0, clip_reward=10.0, gamma=0.99, epsilon=1e-8), 0)
+        eng.reset()
+        for t in range(T):
+            eng.step(acts[t % 4])
+        got = [eng.obs.clone(), eng.reward.clone(), eng.done.clone(), eng.counter.clone()]
+        if precision == "lockstep":
+            got.append(eng.state_f64().clone())
+        if norm:
+            got += [eng.obs_norm.clone(), torch.from_numpy(eng.get_norm_stats())]
+        assert eng.poll_error() == 0
+        got.append(torch.from_numpy(np.asarray(eng.episode_stats(), np.float64)))
+        del eng
+        if want is None:
+            want = got
+            assert float(want[-1][0]) >= 3 * n         # every env finished at least 3 episodes (TimeLimit 9 / 13): the done path is in play
+        else:
+            for a, b in zip(got, want):
+                assert torch.equal(a.cpu().view(torch.uint8) if a.dtype.is_floating_point else a.cpu(), b.cpu().view(torch.uint8) if b.dtype.is_floating_point else b.cpu()), plan
+        torch.cuda.empty_cache()
