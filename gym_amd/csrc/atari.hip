@@ -293,6 +293,40 @@ __global__ __launch_bounds__(kBlock) void materialize_nhwc_kernel(const uint8_t*
     }
 }
 
+// The k = 4 case of both NHWC views, the one every Atari stack uses: a workgroup owns a piece of ONE env's planes (no division per
+// element), a thread takes 4 pixels — one dword from each channel's plane — transposes the 4 x 4 bytes in registers
+// (v_perm_b32) and stores the 16 output bytes as one vector.  `slot0` < 0: channel 0 is zeros (as-written view straight after the
+// first update).  RING_NT / OUT_NT as in the NCHW kernel: ring and view of a 4096-env engine (116 MB each) fit the Infinity Cache
+// and the consumer reads the view next, so both use the default policy there; larger engines stream.
+template <bool STREAM>
+__global__ __launch_bounds__(kBlock) void materialize_nhwc4_kernel(const uint8_t* __restrict__ ring, uint8_t* __restrict__ out, int64_t n, int P4, int split,
+                                                                   int slot0, int slot1, int slot2, int slot3) {
+    using u32x4v = uint32_t __attribute__((ext_vector_type(4)));
+    const int per = (P4 + split - 1) / split;
+    for (int64_t item = blockIdx.x; item < n * split; item += gridDim.x) {
+        const int64_t e = item / split; const int piece = (int)(item - e * split);
+        const uint32_t* env = (const uint32_t*)ring + e * 4 * (int64_t)P4;
+        const uint32_t *p0 = env + (int64_t)(slot0 < 0 ? 0 : slot0) * P4, *p1 = env + (int64_t)slot1 * P4, *p2 = env + (int64_t)slot2 * P4, *p3 = env + (int64_t)slot3 * P4;
+        u32x4v* dst = (u32x4v*)out + e * (int64_t)P4;
+        const int hi = min(P4, (piece + 1) * per);
+        for (int q = piece * per + (int)threadIdx.x; q < hi; q += kBlock) {
+            uint32_t w0, w1, w2, w3;
+            if constexpr (STREAM) { w0 = __builtin_nontemporal_load(p0 + q); w1 = __builtin_nontemporal_load(p1 + q); w2 = __builtin_nontemporal_load(p2 + q); w3 = __builtin_nontemporal_load(p3 + q); }
+            else { w0 = p0[q]; w1 = p1[q]; w2 = p2[q]; w3 = p3[q]; }
+            if (slot0 < 0) w0 = 0u;
+            // __builtin_amdgcn_perm(a, b, sel): selector values 0..3 pick bytes of b, 4..7 bytes of a
+            const uint32_t t0 = __builtin_amdgcn_perm(w1, w0, 0x05010400u), t1 = __builtin_amdgcn_perm(w1, w0, 0x07030602u);   // [w0.b0 w1.b0 w0.b1 w1.b1], [w0.b2 w1.b2 w0.b3 w1.b3]
+            const uint32_t u0 = __builtin_amdgcn_perm(w3, w2, 0x05010400u), u1 = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
+            u32x4v o;
+            o.x = __builtin_amdgcn_perm(u0, t0, 0x05040100u);   // pixel 0: channels 0..3
+            o.y = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+            o.z = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
+            o.w = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+            if constexpr (STREAM) __builtin_nontemporal_store(o, dst + q); else dst[q] = o;
+        }
+    }
+}
+
 // The reference's stack AS WRITTEN (gymhip.h): channel 0 = plane `first_slot` of the ring (or zeros when first_slot < 0),
 // channels 1 .. k-1 = the newest plane.
 __global__ __launch_bounds__(kBlock) void materialize_nhwc_as_written_kernel(const uint8_t* ring, uint8_t* out, int64_t n, int P, int k, int head, int first_slot) {
@@ -680,8 +714,20 @@ int gymhip_atari_materialize_nhwc(gymhip_atari* h, uint8_t* out, void* stream) {
     if (!out) return fail(GYMHIP_EINVAL, "out is null");
     const int P = h->cfg.dst_h * h->cfg.dst_w, k = h->cfg.n_stack;
     const int first = view_first(h);
-    if (first == kViewIntended) hipLaunchKernelGGL(materialize_nhwc_kernel, dim3(2048), dim3(kBlock), 0, (hipStream_t)stream, h->ring, out, h->cfg.n_envs, P, k, h->head);
-    else hipLaunchKernelGGL(materialize_nhwc_as_written_kernel, dim3(2048), dim3(kBlock), 0, (hipStream_t)stream, h->ring, out, h->cfg.n_envs, P, k, h->head, first);
+    hipStream_t s = (hipStream_t)stream;
+    if (k == 4 && ((uintptr_t)out & 15) == 0) {   // dst_w % 4 == 0 (gymhip_atari_create) => P % 4 == 0
+        const int hd = h->head, P4 = P / 4;
+        const int split = std::max(1, std::min(P4, (P4 + 2 * kBlock - 1) / (2 * kBlock)));          // ~2 items per thread
+        const unsigned grid = (unsigned)std::min<int64_t>((int64_t)h->cfg.n_envs * split, 1 << 20);
+        const int s0 = first == kViewIntended ? (hd + 1) & 3 : first, s1 = first == kViewIntended ? (hd + 2) & 3 : hd, s2 = first == kViewIntended ? (hd + 3) & 3 : hd;
+        const size_t ring_bytes = (size_t)h->cfg.n_envs * 4 * P;
+        if (ring_bytes <= kRingKeepBytes / 2) hipLaunchKernelGGL(materialize_nhwc4_kernel<false>, dim3(grid), dim3(kBlock), 0, s, h->ring, out, (int64_t)h->cfg.n_envs, P4, split, s0, s1, s2, hd);
+        else hipLaunchKernelGGL(materialize_nhwc4_kernel<true>, dim3(grid), dim3(kBlock), 0, s, h->ring, out, (int64_t)h->cfg.n_envs, P4, split, s0, s1, s2, hd);
+    } else if (first == kViewIntended) {
+        hipLaunchKernelGGL(materialize_nhwc_kernel, dim3(2048), dim3(kBlock), 0, s, h->ring, out, h->cfg.n_envs, P, k, h->head);
+    } else {
+        hipLaunchKernelGGL(materialize_nhwc_as_written_kernel, dim3(2048), dim3(kBlock), 0, s, h->ring, out, h->cfg.n_envs, P, k, h->head, first);
+    }
     HIP_TRY(hipGetLastError());
     return GYMHIP_OK;
 }

@@ -34,3 +34,8 @@ def timed(fn, nbytes, label, steps=100):
 
 timed(lambda: pp.stacked_nchw_f32(out32), n * 28224 * 5, "materialize_nchw_f32 ")
 timed(lambda: pp.stacked_nchw_16(torch.bfloat16, out16), n * 28224 * 3, "materialize_nchw_bf16")
+out8 = torch.empty((n, 84, 84, 4), dtype=torch.uint8, device="cuda")
+timed(lambda: pp.stacked_nhwc(out8), n * 28224 * 2, "materialize_nhwc_u8  ")
+pp.set_stack_view("as_written")
+out8s = torch.empty((n, 84, 84, 4), dtype=torch.int8, device="cuda")
+timed(lambda: pp.stacked_nhwc(out8s), n * 7056 * 6, "materialize_nhwc_as_written")
