@@ -494,6 +494,15 @@ def main():
         torch.cuda.synchronize()
         ms_mat16 = e0.elapsed_time(e1) / steps
         del out16
+        out8 = torch.empty((n4, 84, 84, 4), dtype=torch.uint8, device="cuda")   # the channels-last uint8 view VecFrameStack itself returns
+        pp.stacked_nhwc(out8)
+        e0.record()
+        for _ in range(steps):
+            pp.stacked_nhwc(out8)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_nhwc = e0.elapsed_time(e1) / steps
+        del out8
         # the same step fed with the emulator's palette-index screens (1 B/pixel) and the in-kernel colour table
         pal = torch.randint(0, 1 << 24, (256,), dtype=torch.int64, generator=torch.Generator().manual_seed(3)).numpy().astype("uint32")
         pp.set_palette(pal)
@@ -517,6 +526,7 @@ def main():
                                     "achieved_GBs": round(bps_idx * n4 / (ms_idx * 1e-3) / 1e9, 1)},
                 "materialize_nchw_bf16_ms": round(ms_mat16, 4),
                 "materialize_nchw_f32_ms": round(ms_mat, 4),
+                "materialize_nhwc_u8_ms": round(ms_nhwc, 4),
                 "materialize_GBs": round((4 * 7056 + 4 * 4 * 7056) * n4 / (ms_mat * 1e-3) / 1e9, 1)}
 
     main_m = measure(args.env, args.mode)
