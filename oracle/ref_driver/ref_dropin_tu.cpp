@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "../../tests/cpp/frame_stack_probe.h"   // run: HipVecFrameStack over a scripted image VecEnv, here on the reference's VecEnvWrapper / spaces
 #include "../../tests/cpp/wrapped_probe.h"   // run_wrapped: the same loop the stand-alone mirror's wrappers are driven by
 
 static_assert(std::is_base_of_v<gym::VecEnv<false>, gym::HipVecEnv>, "HipVecEnv derives from the reference's VecEnv<false>");
@@ -43,6 +44,7 @@ struct CountingWrapper : gym::VecEnvWrapper<false> {
 };
 
 int main(int argc, char** argv) {
+    if (argc == 10 && std::string(argv[1]) == "framestack") return frame_stack_probe::run(argv + 2);   // mode n H W k steps host|device out.bin
     gym::HipVecEnvOptions o;
     o.env_kind = GYMHIP_ENV_CARTPOLE; o.n_envs = 64; o.max_episode_steps = 500; o.monitor = true;
     std::unique_ptr<gym::VecEnv<false>> env = gym::makeTrainingVecNormRO(o);          // gym_.h:15-16 shape

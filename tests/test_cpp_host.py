@@ -245,16 +245,28 @@ def _scripted_image(n, H, W, t):
     return ((v >> np.uint64(8)) & np.uint64(0xFF)).astype(np.uint8).reshape(n, H, W)
 
 
+REF_DROPIN = os.path.join(ROOT, "oracle", "_ref", "ref_dropin_tu")
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("templates", ["mirror", "reference"])
 @pytest.mark.parametrize("mode,where", [("plain", "host"), ("plain", "device"), ("as_written", "host"), ("norm", "device"), ("norm_as_written", "host"), ("clear", "host")])
-def test_hip_vec_frame_stack_cpp_wraps_any_vec_env(oracle, tmp_path, mode, where):
+def test_hip_vec_frame_stack_cpp_wraps_any_vec_env(oracle, tmp_path, mode, where, templates):
     """gym::HipVecFrameStack : VecEnvWrapper<false> (gym/hip_vec_frame_stack.h) held as unique_ptr<VecEnv<false>> over a scripted
     VecEnv<false> of {H, W, 1} byte images: the reference's VecFrameStack, and VecNormAndPermute(VecFrameStack(.)), as wrappers of
-    their own — observation space, every observation against the oracle's frame stack (both views), reward / done untouched."""
-    assert os.path.exists(FS_BIN), "build tests/cpp first"
+    their own — observation space, every observation against the oracle's frame stack (both views), reward / done untouched.
+    "reference": the same probe (tests/cpp/frame_stack_probe.h) compiled with GYMHIP_USE_REFERENCE_HEADERS — the wrapper then derives
+    from the reference's own VecEnvWrapper<false> and builds the reference's own Box spaces (oracle/_ref/ref_dropin_tu framestack)."""
     n, H, W, k, steps = 3, 16, 12, 4, 11
     out = tmp_path / "fs.bin"
-    r = subprocess.run([FS_BIN, mode, str(n), str(H), str(W), str(k), str(steps), where, str(out)], capture_output=True, text=True, timeout=240)
+    if templates == "reference":
+        if not os.path.exists(REF_DROPIN):
+            pytest.skip("oracle/_ref not built (it is built in the container that mounts the reference and travels with the tree)")
+        cmd = [REF_DROPIN, "framestack"]
+    else:
+        assert os.path.exists(FS_BIN), "build tests/cpp first"
+        cmd = [FS_BIN]
+    r = subprocess.run(cmd + [mode, str(n), str(H), str(W), str(k), str(steps), where, str(out)], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     lines = r.stdout.strip().splitlines()
     norm, aw = mode.startswith("norm"), mode.endswith("as_written")
