@@ -15,6 +15,8 @@
 #include "gym/hip_vec_env.h"
 #include "gym/hip_env.h"
 #include "gym/hip_vec_frame_stack.h"
+#include "gym/hip_atari_vec_env.h"
+#include "../../tests/cpp/fake_emulator.h"   // an emulator-shaped type to instantiate gym::HipAtariVecEnv<Emu> with
 
 #include <cstdio>
 #include <cstdlib>
@@ -37,6 +39,9 @@ using WrappedSingle = gym::Monitor<gym::TimeLimit<gym::HipCartPoleEnv>, true>;
 static_assert(std::is_base_of_v<gym::VecEnvWrapper<false>, gym::HipTrainingVecNormRO>, "the normaliser wrapper class derives from the reference's VecEnvWrapper<false>, as VecNormalize does (vec_normalize.h:21)");
 static_assert(std::is_base_of_v<gym::VecEnvWrapper<false>, gym::HipVecFrameStack> && !std::is_abstract_v<gym::HipVecFrameStack>,
               "the frame-stack wrapper derives from the reference's VecEnvWrapper<false>, as VecFrameStack does (vec_frame_stack.h:16)");
+static_assert(std::is_base_of_v<gym::VecEnv<false>, gym::HipAtariVecEnv<FakeEmulator>> && !std::is_abstract_v<gym::HipAtariVecEnv<FakeEmulator>>,
+              "the Atari stack is a VecEnv<false> of the reference's, as the trainer holds it (test/atari_env.cpp:48-60)");
+template class gym::HipAtariVecEnv<FakeEmulator>;   // every member compiled against the reference's headers, not only the ones a caller here touches
 struct CountingWrapper : gym::VecEnvWrapper<false> {
     using gym::VecEnvWrapper<false>::VecEnvWrapper;
     int steps = 0;
