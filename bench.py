@@ -411,6 +411,25 @@ def main():
                 "rollout_500_steps_per_launch": {"value": n2 / roll, "unit": "env-steps/s (per GPU)", "us_per_step": round(roll * 1e6, 3)},
                 "error_flag": err}
 
+    def measure_rollout_big(K=32):
+        """The harness form at the headline size: gymhip_rollout, K steps per launch from a u8 action tape with the (exact, fp64) state in
+        registers and no per-step observation / reward / done traffic — what the arithmetic alone allows; NOT the VecEnv::step path."""
+        eng, _ = build("cartpole", "lockstep", "rng")
+        g = torch.Generator(device="cuda").manual_seed(11 + rank)
+        tape = torch.randint(0, 2, (K, n), dtype=torch.uint8, device="cuda", generator=g)
+        eng.rollout(tape)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            eng.rollout(tape)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        err = eng.poll_error()
+        eng.close()
+        del tape
+        return {"value": n * K / (ms * 1e-3), "unit": "env-steps/s (per GPU)", "envs": n, "steps_per_launch": K, "us_per_step": round(ms / K * 1e3, 2), "error_flag": err}
+
     def measure_pcie_inclusive(steps):
         """What the rates become if a caller keeps actions / results / frames on the HOST (never `value`):
         (a) the headline CartPole step with int32 actions from pinned host memory and obs/reward/done copied back to it;
@@ -609,6 +628,7 @@ def main():
             guarded(f"{env}_{mode}", classic, env, mode)
         guarded(f"cartpole_f32_{other}_resets", classic, "cartpole", "f32", other)
         guarded("config2_cartpole_lockstep_65536", measure_config2)
+        guarded("cartpole_lockstep_rollout_32_steps_per_launch", measure_rollout_big)
         guarded("config3_mountaincar_vecnormalize_131072_per_gpu", measure_config3, 1 << 17, max(args.steps, 500))   # configs[2]'s per-GPU shard on 8 GPUs
         guarded("config3_mountaincar_vecnormalize_1M_per_gpu", measure_config3, 1 << 20, max(args.steps, 200))
         guarded("config3_mountaincar_vecnormalize_16M_per_gpu", measure_config3, 1 << 24, max(20, args.steps // 4))
