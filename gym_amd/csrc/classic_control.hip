@@ -51,9 +51,10 @@ namespace {
 #define GYMHIP_BLOCK 512
 #endif
 constexpr int kBlock = GYMHIP_BLOCK;   // 512: equal to 256 on the headline kernel, best on the normaliser pair (profiles/r02_sweep_block.txt)
-constexpr int kMaxGrid = 8192;  // upper bound of the grid-stride launch (sizes the per-block partial buffers)
+constexpr int kMaxGrid = 16384; // upper bound of the grid-stride launch (sizes the per-block episode-counter rows)
 constexpr int kDefaultGrid = 512;   // 256 CUs x 2 blocks of 512 threads: best for the float-state and MountainCar kernels and for normaliser engines (fewer partial rows to fold); GYMHIP_GRID overrides
 constexpr int kPlainGrid = 2048;    // CartPole lockstep without the normaliser (the 84-B kernel): 1024 .. 4096 measure alike, 1.5 % above 512 (profiles/r02_sweeps.txt)
+constexpr int kStreamGrid = 16384;  // the same kernel once it streams non-temporally (residency plan): 2 envs per thread, +2 % over 2048 at 8 .. 33 M envs; the other kernels lose there
 constexpr size_t kNtFootprint = (size_t)336 << 20;   // bytes; see gymhip_create
 constexpr size_t kMallBudget = (size_t)240 << 20;    // bytes of the 256 MiB Infinity Cache a residency plan fills (plan_residency)
 enum : int { kKeepCounter = 1, kKeepReward = 2, kKeepDone = 4, kKeepReturns = 8, kKeepNotDone = 11, kKeepAll = 15 };
@@ -1028,7 +1029,7 @@ bool valid_config(const gymhip_config* c) {
 }
 
 // Launch shape of the step / reset / rollout kernels: `grid` workgroups of kBlock threads of which the first `lanes` own envs.
-int grid_for(int64_t n, bool norm, bool cartpole_lockstep, int* lanes) {
+int grid_for(int64_t n, bool norm, bool cartpole_lockstep, bool streaming, int* lanes) {
     *lanes = kBlock;
     int64_t cap = (!norm && cartpole_lockstep) ? kPlainGrid : kDefaultGrid;
     if (const char* e = getenv("GYMHIP_GRID")) { int v = atoi(e); if (v > 0 && v <= kMaxGrid) return (int)std::min<int64_t>(v, (n + kBlock - 1) / kBlock); }
@@ -1047,6 +1048,7 @@ int grid_for(int64_t n, bool norm, bool cartpole_lockstep, int* lanes) {
     // One env per thread until every CU has a block (256); then up to 8 envs per thread before the grid grows to its cap: at
     // the 131,072 .. 1 M envs per GPU of BASELINE configs[2] fewer blocks mean fewer partial rows for the normalise kernel to fold.
     if (one_per_thread <= 256) return (int)one_per_thread;
+    if (!norm && cartpole_lockstep && streaming) return (int)std::min<int64_t>(kStreamGrid, std::max<int64_t>(256, (n + (int64_t)kBlock * 2 - 1) / ((int64_t)kBlock * 2)));
     const int64_t g = (n + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8);
     return (int)std::min<int64_t>(cap, std::max<int64_t>(256, g));
 }
@@ -1317,7 +1319,6 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
     h->F = obs_dim_of(cfg->env_kind);
     h->L = make_layout(*cfg);
     h->norm = cfg->wrappers & (GYMHIP_WRAP_NORM_OBS | GYMHIP_WRAP_NORM_REWARD);
-    h->grid = grid_for(cfg->n_envs, h->norm, cfg->env_kind == KIND_CARTPOLE && cfg->precision == GYMHIP_PRECISION_LOCKSTEP_F64, &h->lanes);
     h->tape = nullptr; h->tape_episodes = 0; h->tape_source = 0; h->tape_seeded = false; h->tape_seed = 0;
     h->did_reset = false; h->pending_finish = false; h->pending_is_reset = false;
     // Non-temporal streaming pays only once the per-step footprint (workspace + an int32 action row) no longer fits the
@@ -1325,6 +1326,7 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
     size_t nt_footprint = kNtFootprint;
     if (const char* e = getenv("GYMHIP_NT_MB")) nt_footprint = (size_t)std::max(0, atoi(e)) << 20;   // sweeps only
     h->stream_nt = kNtDefault && h->L.total + (size_t)cfg->n_envs * 4 > nt_footprint;
+    h->grid = grid_for(cfg->n_envs, h->norm, cfg->env_kind == KIND_CARTPOLE && cfg->precision == GYMHIP_PRECISION_LOCKSTEP_F64, h->stream_nt && cfg->reset_mode != GYMHIP_RESET_TAPE /* tape engines measure alike at 2048 and 16384 */, &h->lanes);
     plan_residency(h);
     if (int rc = resolve_scratch(device, &h->scratch_dev)) { delete h; return rc; }
     if (workspace) {

@@ -90,6 +90,20 @@ template <int MASK, bool MERGED> __global__ __launch_bounds__(512) void subset_k
     }
 }
 
+// The wide rows out of place: read obs / residual from one pair of arrays, write the other pair (a ping-pong state), + the action read.
+__global__ __launch_bounds__(512) void pingpong_kernel(const f32x4* __restrict__ obs_in, const i32x4* __restrict__ res_in, const int32_t* __restrict__ act,
+                                                       f32x4* __restrict__ obs_out, i32x4* __restrict__ res_out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 512;
+    int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x;
+    f32x4 o{}, on{}; i32x4 k{}, kn{}; int32_t a = 0, an = 0;
+    if (i < n) { o = ld<true>(obs_in + i); k = ld<true>(res_in + i); a = ld<true>(act + i); }
+    for (; i < n; i += stride) {
+        if (i + stride < n) { on = ld<true>(obs_in + i + stride); kn = ld<true>(res_in + i + stride); an = ld<true>(act + i + stride); }
+        st<true>(obs_out + i, o * 1.0001f + (float)a); st<true>(res_out + i, k + 1);
+        o = on; k = kn; a = an;
+    }
+}
+
 template <typename F> static double time_ms(F&& launch, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int i = 0; i < 5; i++) launch();
@@ -150,6 +164,23 @@ int main(int argc, char** argv) {
         run("obs + residual only (16-B streams)", 64, subset_kernel<3, false>, p[1]);
         run("the 4-B streams only", 20, subset_kernel<60, false>, p[1]);
         run("obs only", 32, subset_kernel<1, false>, p[1]);
+        run("obs + residual in place + action read (68 B): what still streams under the residency plan", 68, subset_kernel<11, false>, p[1]);
+        {
+            char* alt; CK(hipMalloc(&alt, n * 32)); CK(hipMemset(alt, 0, n * 32));
+            for (int grid : {1024, 2048, 4096, 16384}) {
+                bool flip = false;
+                const double ms = time_ms([&] {
+                    if (flip) pingpong_kernel<<<grid, 512>>>((const f32x4*)alt, (const i32x4*)(alt + n * 16), (const int32_t*)p[2], (f32x4*)p[0], (i32x4*)p[1], n);
+                    else pingpong_kernel<<<grid, 512>>>((const f32x4*)p[0], (const i32x4*)p[1], (const int32_t*)p[2], (f32x4*)alt, (i32x4*)(alt + n * 16), n);
+                    flip = !flip; }, reps);
+                std::printf("%-44s grid %5d  %.4f ms  %5.0f B/env  %.0f GB/s  %.3f of 8 TB/s\n", "obs + residual OUT OF PLACE (ping-pong) + action", grid, ms, 68.0, 68.0 * n / ms / 1e6, 68.0 * n / ms / 1e6 / 8000.0);
+            }
+            for (int grid : {1024, 16384}) {
+                const double ms = time_ms([&] { subset_kernel<11, false><<<grid, 512>>>((f32x4*)p[0], (i32x4*)p[1], (const int32_t*)p[2], (uint32_t*)p[3], (float*)p[4], (float*)p[5], n); }, reps);
+                std::printf("%-44s grid %5d  %.4f ms  %5.0f B/env  %.0f GB/s  %.3f of 8 TB/s\n", "obs + residual in place + action", grid, ms, 68.0, 68.0 * n / ms / 1e6, 68.0 * n / ms / 1e6 / 8000.0);
+            }
+            CK(hipFree(alt));
+        }
         CK(hipFree(slab2));
     }
     CK(hipDeviceSynchronize());
