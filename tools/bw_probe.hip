@@ -63,7 +63,7 @@ template <int V, bool NT, bool PIPE> __global__ __launch_bounds__(512) void mix_
 
 // Which streams cost what: MASK bit 0 = obs rw, 1 = residual rw, 2 = counter rw, 3 = action r, 4 = reward w, 5 = done w.
 // MERGED: residual and counter live in ONE array of 64-env tiles [64 x 16 B residual | 64 x 4 B counter] (1280 B per tile).
-template <int MASK, bool MERGED> __global__ __launch_bounds__(512) void subset_kernel(f32x4* obs, i32x4* res, const int32_t* __restrict__ act, uint32_t* ctr,
+template <int MASK, bool MERGED, bool KEEP_LANES = false> __global__ __launch_bounds__(512) void subset_kernel(f32x4* obs, i32x4* res, const int32_t* __restrict__ act, uint32_t* ctr,
                                                                                         float* rew, float* done, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * 512;
     struct In { f32x4 o; i32x4 k; int32_t a; uint32_t w; };
@@ -73,7 +73,7 @@ template <int MASK, bool MERGED> __global__ __launch_bounds__(512) void subset_k
         if (MASK & 1) in.o = ld<true>(obs + i);
         if (MASK & 2) in.k = ld<true>(res_ptr(i));
         if (MASK & 8) in.a = ld<true>(act + i);
-        if (MASK & 4) in.w = ld<true>(ctr_ptr(i));
+        if (MASK & 4) in.w = ld<!KEEP_LANES>(ctr_ptr(i));
     };
     int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x;
     In cur{}, nxt{};
@@ -83,9 +83,9 @@ template <int MASK, bool MERGED> __global__ __launch_bounds__(512) void subset_k
         if (MASK & 1) st<true>(obs + i, cur.o * 1.0001f);
         if (MASK & 2) st<true>(res_ptr(i), cur.k + 1);
         const uint32_t w = cur.w + 1u;
-        if (MASK & 4) st<true>(ctr_ptr(i), w);
-        if (MASK & 16) st<true>(rew + i, (float)cur.a + cur.o.x);
-        if (MASK & 32) st<true>(done + i, (float)(w & 1u));
+        if (MASK & 4) st<!KEEP_LANES>(ctr_ptr(i), w);
+        if (MASK & 16) st<!KEEP_LANES>(rew + i, (float)cur.a + cur.o.x);
+        if (MASK & 32) st<!KEEP_LANES>(done + i, (float)(w & 1u));
         cur = nxt;
     }
 }
@@ -174,6 +174,10 @@ int main(int argc, char** argv) {
                     else pingpong_kernel<<<grid, 512>>>((const f32x4*)p[0], (const i32x4*)p[1], (const int32_t*)p[2], (f32x4*)alt, (i32x4*)(alt + n * 16), n);
                     flip = !flip; }, reps);
                 std::printf("%-44s grid %5d  %.4f ms  %5.0f B/env  %.0f GB/s  %.3f of 8 TB/s\n", "obs + residual OUT OF PLACE (ping-pong) + action", grid, ms, 68.0, 68.0 * n / ms / 1e6, 68.0 * n / ms / 1e6 / 8000.0);
+            }
+            for (int grid : {2048, 4096, 8192, 16384}) {   // the residency plan without arithmetic: all six streams, the 4-B lanes with the default cache policy
+                const double ms = time_ms([&] { subset_kernel<63, false, true><<<grid, 512>>>((f32x4*)p[0], (i32x4*)p[1], (const int32_t*)p[2], (uint32_t*)p[3], (float*)p[4], (float*)p[5], n); }, reps);
+                std::printf("%-44s grid %5d  %.4f ms  %5.0f B/env  %.0f GB/s  %.3f of 8 TB/s\n", "all six streams, lanes kept in the cache", grid, ms, 84.0, 84.0 * n / ms / 1e6, 84.0 * n / ms / 1e6 / 8000.0);
             }
             for (int grid : {1024, 16384}) {
                 const double ms = time_ms([&] { subset_kernel<11, false><<<grid, 512>>>((f32x4*)p[0], (i32x4*)p[1], (const int32_t*)p[2], (uint32_t*)p[3], (float*)p[4], (float*)p[5], n); }, reps);
