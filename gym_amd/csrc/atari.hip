@@ -366,8 +366,8 @@ template <int SGN> __device__ inline float px(uint32_t w, int b) {
 template <int BF16, int SGN> __device__ inline uint32_t pack16(uint32_t w, int b) { return to16<BF16>(px<SGN>(w, b)) | (to16<BF16>(px<SGN>(w, b + 1)) << 16); }
 
 // MODE 0: f32 out, 4 px per item.  MODE 1: 16-bit out, 8 px per item.  MODE 2: 16-bit out, 4 px per item (P % 8 != 0).
-#ifndef GYMHIP_MAT_BLOCK
 constexpr int kViewIntended = -2;   // `first` argument of the materialise kernels: the intended shift view
+#ifndef GYMHIP_MAT_BLOCK
 #define GYMHIP_MAT_BLOCK 256
 #endif
 #ifndef GYMHIP_MAT_UNR
@@ -517,8 +517,9 @@ int view_first(const gymhip_atari* h) {
 // Launch shape of the NCHW materialisation: `split` workgroups per (env, channel) plane, at most kMatMaxGrid workgroups (a
 // grid-stride loop covers the rest).  GYMHIP_MAT_SPLIT / GYMHIP_MAT_GRID override for sweeps (tools/sweep_materialize.sh).
 constexpr int kMatMaxGrid = 1 << 20;
-void materialize_shape(int64_t planes, int items, int* split, unsigned* grid) {
+void materialize_shape(int64_t planes, int items, bool ring_kept, int* split, unsigned* grid) {
     int sp = (int)((2 * (int64_t)items + 7 * kMatBlock / 2) / (7 * kMatBlock));   // default: ~3.5 items per thread (14 KB out per workgroup), best of tools/sweep_materialize.sh
+    if (ring_kept) sp = 1;   // with the ring served by the Infinity Cache one workgroup per plane wins for both views (f32: 0.099 -> 0.084 ms, profiles/r02_sweeps.txt)
     if (const char* e = getenv("GYMHIP_MAT_SPLIT")) { const int v = atoi(e); if (v > 0) sp = v; }
     sp = std::max(1, std::min(sp, items));
     int64_t g = planes * sp;
@@ -534,7 +535,7 @@ template <int MODE, int BF16, bool RING_NT> int launch_nchw_policy(gymhip_atari*
     const int P = h->cfg.dst_h * h->cfg.dst_w, k = h->cfg.n_stack;
     const int64_t planes = h->cfg.n_envs * k;
     int split; unsigned grid;
-    materialize_shape(planes, P / px_per_item, &split, &grid);
+    materialize_shape(planes, P / px_per_item, !RING_NT, &split, &grid);
     if (h->view == GYMHIP_STACK_AS_WRITTEN) {
         // straight after reset() the stack is [0, .., 0, f] in both views: the intended mapping, with the signed reading (AW = 2)
         const int first = view_first(h);
