@@ -55,7 +55,7 @@ constexpr int kMaxGrid = 16384; // upper bound of the grid-stride launch (sizes 
 constexpr int kDefaultGrid = 512;   // 256 CUs x 2 blocks of 512 threads: best for the float-state and MountainCar kernels and for normaliser engines (fewer partial rows to fold); GYMHIP_GRID overrides
 constexpr int kPlainGrid = 2048;    // CartPole lockstep without the normaliser (the 84-B kernel): 1024 .. 4096 measure alike, 1.5 % above 512 (profiles/r02_sweeps.txt)
 constexpr int kStreamGrid = 16384;  // the same kernel once it streams non-temporally (residency plan): 2 envs per thread, +2 % over 2048 at 8 .. 33 M envs; the other kernels lose there
-constexpr size_t kNtFootprint = (size_t)336 << 20;   // bytes; see gymhip_create
+constexpr size_t kNtFootprint = (size_t)256 << 20;   // bytes (the Infinity Cache); see gymhip_create
 constexpr size_t kMallBudget = (size_t)240 << 20;    // bytes of the 256 MiB Infinity Cache a residency plan fills (plan_residency)
 enum : int { kKeepCounter = 1, kKeepReward = 2, kKeepDone = 4, kKeepReturns = 8, kKeepNotDone = 11, kKeepAll = 15 };
 constexpr int kPlans[] = {kKeepAll, kKeepNotDone, kKeepCounter, 0};   // the plans the step kernel is compiled for, most bytes kept first
@@ -1321,11 +1321,14 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
     h->norm = cfg->wrappers & (GYMHIP_WRAP_NORM_OBS | GYMHIP_WRAP_NORM_REWARD);
     h->tape = nullptr; h->tape_episodes = 0; h->tape_source = 0; h->tape_seeded = false; h->tape_seed = 0;
     h->did_reset = false; h->pending_finish = false; h->pending_is_reset = false;
-    // Non-temporal streaming pays only once the per-step footprint (workspace + an int32 action row) no longer fits the
-    // 256 MiB Infinity Cache; measured crossover on MI355X between 302 MB (temporal +14 %) and 403 MB (non-temporal +6 %).
+    // Plain (temporal) accesses win while everything a step touches stays in the 256 MiB Infinity Cache from one step to the next;
+    // beyond that they thrash it and the engine streams non-temporally under a residency plan (plan_residency).  "Everything" is
+    // the workspace plus the callers' action rows — the bench rotates four int32 rows, a trainer's policy has its own traffic — so
+    // the footprint counts 16 B of actions per env.  Measured crossovers (tools/sweep_nt_threshold.sh): CartPole lockstep between
+    // 4.2 M (plain 0.79 | streaming 0.71) and 5.2 M envs (0.64 | 0.79); MountainCar lockstep between 5.8 M (0.79 | 0.75) and 6.3 M (0.67 | 0.74).
     size_t nt_footprint = kNtFootprint;
     if (const char* e = getenv("GYMHIP_NT_MB")) nt_footprint = (size_t)std::max(0, atoi(e)) << 20;   // sweeps only
-    h->stream_nt = kNtDefault && h->L.total + (size_t)cfg->n_envs * 4 > nt_footprint;
+    h->stream_nt = kNtDefault && h->L.total + (size_t)cfg->n_envs * 16 > nt_footprint;
     h->grid = grid_for(cfg->n_envs, h->norm, cfg->env_kind == KIND_CARTPOLE && cfg->precision == GYMHIP_PRECISION_LOCKSTEP_F64, h->stream_nt && cfg->reset_mode != GYMHIP_RESET_TAPE /* tape engines measure alike at 2048 and 16384 */, &h->lanes);
     plan_residency(h);
     if (int rc = resolve_scratch(device, &h->scratch_dev)) { delete h; return rc; }
