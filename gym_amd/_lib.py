@@ -121,6 +121,7 @@ SIGNATURES = {
     "gymhip_atari_preprocess_indexed": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gymhip_atari_reset_indexed": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_step_indexed": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "gymhip_launch_info": (C.c_int, [_vp, _vp]),
     "gymhip_atari_push_reset": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_push": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gymhip_atari_materialize_nhwc": (C.c_int, [_vp, _vp, _vp]),

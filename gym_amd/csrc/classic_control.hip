@@ -1631,6 +1631,12 @@ int gymhip_poll_error(gymhip_engine* h, int32_t* host_out, void* stream) {
     return GYMHIP_OK;
 }
 
+int gymhip_launch_info(gymhip_engine* h, int32_t out[4]) {
+    if (!h || !out) return fail(GYMHIP_EINVAL, "null argument");
+    out[0] = h->grid; out[1] = h->lanes; out[2] = h->stream_nt ? 1 : 0; out[3] = h->stream_nt ? h->keep_small : 0;
+    return GYMHIP_OK;
+}
+
 int gymhip_reset_index(gymhip_engine* h, int64_t index, void* stream) {
     if (int rc = check_handle(h)) return rc;
     if (index < 0 || index >= h->cfg.n_envs) return fail(GYMHIP_EINVAL, "env index %lld out of range [0, %lld)", (long long)index, (long long)h->cfg.n_envs);

@@ -207,6 +207,12 @@ class Engine:
         L.check(self.lib.gymhip_episode_stats(self.h, out.ctypes.data_as(C.c_void_p), self._stream()), "gymhip_episode_stats")
         return out
 
+    def launch_info(self) -> dict:
+        """The launch shape and cache policy gymhip_create chose (gymhip_launch_info): speed only, never results."""
+        out = (C.c_int32 * 4)()
+        L.check(self.lib.gymhip_launch_info(self.h, out), "gymhip_launch_info")
+        return {"grid": out[0], "lanes": out[1], "streams_non_temporally": bool(out[2]), "kept_lanes": out[3]}
+
     def poll_error(self) -> int:
         v = C.c_int32(0)
         L.check(self.lib.gymhip_poll_error(self.h, C.byref(v), self._stream()), "gymhip_poll_error")

@@ -180,6 +180,11 @@ int gymhip_episode_stats(gymhip_engine* h, double* host_out, void* stream);
  * range (non-finite, or nonzero below 2^-126 — the dynamics never produce either), bit3 = with GYMHIP_WRAP_NO_AUTO_RESET a
  * finished env was stepped again before its gymhip_reset_index(). */
 int gymhip_poll_error(gymhip_engine* h, int32_t* host_out, void* stream);
+/* Diagnostics, no counterpart in the reference: the launch shape and cache policy gymhip_create chose for this engine
+ *  — out[0] = workgroups of the step / reset kernels, out[1] = threads per workgroup that own envs,
+ * out[2] = 1 when the engine streams non-temporally (its per-step footprint does not fit the Infinity Cache), out[3] = its
+ * residency plan: the 4-byte lanes kept in that cache, bit 0 counter, 1 reward, 2 done, 3 returns.  Speed only, never results. */
+int gymhip_launch_info(gymhip_engine* h, int32_t out[4]);
 
 /* VecEnv::reset(int index) (base.h:54; sync_env.h:128-139) under VecNormalize::reset(int index) (vec_normalize.h:179-189):
  * env `index` alone is reset (it consumes its next reset-tape row / a fresh stateless draw), its return lane is zeroed,

@@ -204,3 +204,30 @@ def test_every_residency_plan_computes_the_same_bits(monkeypatch, kind, precisio
             for a, b in zip(got, want):
                 assert torch.equal(a.cpu().view(torch.uint8) if a.dtype.is_floating_point else a.cpu(), b.cpu().view(torch.uint8) if b.dtype.is_floating_point else b.cpu()), plan
         torch.cuda.empty_cache()
+
+
+def test_launch_shape_and_cache_policy_follow_the_engine_size():
+    """gymhip_launch_info: what gymhip_create chose, against DESIGN.md §4 — small engines spread over 256 workgroups, plain accesses
+    while the step's footprint fits the Infinity Cache, beyond it a residency plan (all 4-byte lanes while they fit 240 MiB, tape
+    engines all but done, then fewer), and the headline kernel's 2-envs-per-thread shape once it streams."""
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+
+    def info(n, kind=L.ENV_CARTPOLE, precision=L.PRECISION_LOCKSTEP_F64, reset=L.RESET_COUNTER_RNG, norm=False):
+        w = L.WRAP_TIME_LIMIT | L.WRAP_MONITOR | ((L.WRAP_NORM_OBS | L.WRAP_NORM_REWARD | L.WRAP_NORM_TRAINING) if norm else 0)
+        e = Engine(EngineConfig(env_kind=kind, n_envs=n, precision=precision, reset_mode=reset, wrappers=w, max_episode_steps=200, seed=0,
+                                clip_obs=10.0, clip_reward=10.0, gamma=0.99, epsilon=1e-8), 0)
+        i = e.launch_info()
+        e.close()
+        torch.cuda.empty_cache()
+        return i
+
+    assert info(65536) == {"grid": 256, "lanes": 256, "streams_non_temporally": False, "kept_lanes": 0}                       # configs[1]
+    assert info(1 << 17, L.ENV_MOUNTAINCAR, norm=True) == {"grid": 256, "lanes": 512, "streams_non_temporally": False, "kept_lanes": 0}   # configs[2]'s shard
+    assert info(4 << 20)["streams_non_temporally"] is False
+    assert info(6 << 20) == {"grid": 6144, "lanes": 512, "streams_non_temporally": True, "kept_lanes": 15}
+    assert info(N_FULL) == {"grid": 16384, "lanes": 512, "streams_non_temporally": True, "kept_lanes": 15}                     # the headline engine
+    assert info(N_FULL, reset=L.RESET_TAPE) == {"grid": 2048, "lanes": 512, "streams_non_temporally": True, "kept_lanes": 11}
+    assert info(N_FULL, precision=L.PRECISION_F32) == {"grid": 512, "lanes": 512, "streams_non_temporally": True, "kept_lanes": 15}
+    assert info(N_FULL, L.ENV_MOUNTAINCAR, norm=True) == {"grid": 512, "lanes": 512, "streams_non_temporally": True, "kept_lanes": 11}   # four lanes = 256 MiB: done streams
+    assert info(32 << 20)["kept_lanes"] == 1 and info(96 << 20, L.ENV_MOUNTAINCAR, precision=L.PRECISION_F32)["kept_lanes"] == 0
