@@ -329,6 +329,27 @@ def main():
             "achieved_gbs": achieved, "bytes_per_env_step": bps, "error_flag": err, "episodes": eps[0],
         }
 
+    def measure_cache_swept(steps=40):
+        """The headline step when something else sweeps the 256 MiB Infinity Cache between two steps (here a 512 MiB read-modify-write
+        with the default cache policy, standing in for a trainer's policy network): the residency plan's lanes are then fetched
+        from HBM again.  Only the step kernel is timed (HIP events around it); the sweep is not."""
+        eng, acts = build("cartpole", "lockstep", "rng")
+        scratch = torch.zeros(128 << 20, dtype=torch.float32, device="cuda")
+        for k in range(5):
+            scratch.add_(1.0); eng.step(acts[k % len(acts)])
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for k in range(steps):
+            scratch.add_(1.0)
+            ev[k][0].record(); eng.step(acts[k % len(acts)]); ev[k][1].record()
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        eng.close()
+        del scratch, eng, acts
+        torch.cuda.empty_cache()
+        gbs = BYTES_PER_STEP[("cartpole", "lockstep")] * n / (ms * 1e-3) / 1e9
+        return {"kernel_ms": round(ms, 4), "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "note": "not `value`: a 512 MiB cache sweep runs between the steps; the step kernel alone is timed"}
+
     def measure_config3(n3, steps):
         """BASELINE configs[2]: MountainCar + TimeLimit(200) + ClipReward + Monitor + obs/return normaliser; with more than one
         rank the per-step batch moments + episode statistics (12 doubles) are all-reduced over RCCL between the step and the
@@ -627,6 +648,7 @@ def main():
         for env, mode in (("cartpole", "f32"), ("mountaincar", "lockstep"), ("mountaincar", "f32")):
             guarded(f"{env}_{mode}", classic, env, mode)
         guarded(f"cartpole_f32_{other}_resets", classic, "cartpole", "f32", other)
+        guarded("cartpole_lockstep_cache_swept_between_steps", measure_cache_swept)
         guarded("config2_cartpole_lockstep_65536", measure_config2)
         guarded("cartpole_lockstep_rollout_32_steps_per_launch", measure_rollout_big)
         guarded("config3_mountaincar_vecnormalize_131072_per_gpu", measure_config3, 1 << 17, max(args.steps, 500))   # configs[2]'s per-GPU shard on 8 GPUs
