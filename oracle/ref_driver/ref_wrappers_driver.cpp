@@ -13,6 +13,8 @@
 #include "wrappers/clip_reward.h"
 #include "wrappers/monitor.h"
 #include "common/normalizers/running_mean_std.h"
+#include <cassert>
+#include "wrappers/vec_env/updateable.h"
 
 #include <cstdio>
 #include <cstring>

@@ -94,7 +94,8 @@ struct HalfObs : gym::ObservationWrapper2<ScriptEnv, float> {   // changes the o
     float observation(std::vector<double>&& x) const noexcept override { return float(0.5 * x[0] - 3.0); }
 };
 
-// out: rows of {f64 obs, f32 reward, u8 done, f32 obs2, f32 reward2, u8 done2}; row 0 is the reset; then int64 wrapped()->t, int64 has_spaces
+// out: rows of {f64 obs, f32 reward, u8 done, f32 obs2, f32 reward2, u8 done2}; row 0 is the reset; then int64 wrapped()->t, int64 has_spaces,
+// then four int64 of the Updater probe: first subscriber's sum and calls, second subscriber's sum and calls
 inline int run_unroll(const char* in, const char* out) {
     FILE* f = fopen(in, "rb"); if (!f) return 2;
     int64_t L, max_steps, steps, flags;
@@ -124,6 +125,15 @@ inline int run_unroll(const char* in, const char* out) {
     }
     int64_t t = (int64_t)half.wrapped()->t, has_spaces = (chain.observationSpace() ? 1 : 0) + (half.actionSpace() ? 2 : 0) + (half.info() == inner->info() ? 4 : 0);
     fwrite(&t, 8, 1, o); fwrite(&has_spaces, 8, 1, o);
+    // Updater / Updateable (wrappers/vec_env/updateable.h:10-31): notifyOne tells only the FIRST subscriber
+    struct Sum : gym::Updateable<int> { int64_t total = 0, calls = 0; void update(int&& v) override { total += v; calls++; } };
+    Sum first, second;
+    gym::Updater<int> updater;
+    updater.notifyOne(100);                        // nobody subscribed yet: dropped
+    updater.subscribe(&first); updater.subscribe(&second);
+    for (int v : {5, 7, 11}) updater.notifyOne(std::move(v));
+    const int64_t upd[4] = {first.total, first.calls, second.total, second.calls};
+    fwrite(upd, 8, 4, o);
     fclose(o);
     return 0;
 }

@@ -49,8 +49,8 @@ def run_unroll(rew, done, steps, driver=None):
         subprocess.run([driver or DRIVER, "unroll", fin, fout], check=True, capture_output=True)
         raw = open(fout, "rb").read()
     n = (steps + 1) * UNROLL.itemsize
-    t, flags = np.frombuffer(raw[n:], np.int64)
-    return np.frombuffer(raw[:n], UNROLL), int(t), int(flags)
+    t, flags, *updater = np.frombuffer(raw[n:], np.int64)
+    return np.frombuffer(raw[:n], UNROLL), int(t), int(flags), [int(x) for x in updater]
 
 
 def rms_batches(seed, nb, F):
@@ -125,8 +125,9 @@ def main():
     np.savez_compressed(os.path.join(OUT, "ref_wrappers.npz"), script_seed=11, script_len=997, max_steps=13, steps=4000,
                         **{k: rec[k] for k in REC.names})
     rew, done = wrapper_script(12, 211)
-    rows, t, flags = run_unroll(rew, done, 1000)
-    np.savez_compressed(os.path.join(OUT, "ref_unroll.npz"), script_seed=12, script_len=211, steps=1000, t=t, flags=flags, **{k: rows[k] for k in UNROLL.names})
+    rows, t, flags, updater = run_unroll(rew, done, 1000)
+    np.savez_compressed(os.path.join(OUT, "ref_unroll.npz"), script_seed=12, script_len=211, steps=1000, t=t, flags=flags, updater=np.array(updater, np.int64),
+                        **{k: rows[k] for k in UNROLL.names})
     F = 4
     rows = run_rms(rms_batches(5, 30, F), F)
     np.savez_compressed(os.path.join(OUT, "ref_rms.npz"), batch_seed=5, n_batches=30, F=F, rows=rows)

@@ -189,12 +189,14 @@ def test_cpp_wrapper_unroll_and_observation_wrapper2_mirror_equal_the_references
     assert os.path.exists(MIRROR_WRAPPERS), "build tests/cpp first"
     g = np.load(os.path.join(G, "ref_unroll.npz"))
     rew, done = R.wrapper_script(int(g["script_seed"]), int(g["script_len"]))
-    rows, t, flags = R.run_unroll(rew, done, int(g["steps"]), driver=MIRROR_WRAPPERS)
+    rows, t, flags, updater = R.run_unroll(rew, done, int(g["steps"]), driver=MIRROR_WRAPPERS)
     want = unroll_expected(rew, done, int(g["steps"]))
     assert int(g["done"].sum()) > 30
     for name in R.UNROLL.names:
         assert rows[name].tobytes() == np.ascontiguousarray(g[name]).tobytes() == want[name].tobytes(), name
     assert (t, flags) == (int(g["t"]), int(g["flags"])) == (int(g["steps"]), 4)     # no spaces on a bare scripted env; info() forwarded
+    # Updater::notifyOne (updateable.h:26-29): only the FIRST subscriber is told; nothing is queued before a subscription
+    assert updater == list(g["updater"]) == [23, 3, 0, 0]
 
 
 @pytest.mark.skipif(not HAVE_DRIVER, reason="oracle/_ref not built (needs /root/reference; build container only)")
@@ -202,7 +204,7 @@ def test_cpp_wrapper_unroll_mirror_vs_live_reference_driver():
     for seed, L, steps in ((5, 17, 300), (6, 400, 900)):
         rew, done = R.wrapper_script(seed, L)
         a, b = R.run_unroll(rew, done, steps), R.run_unroll(rew, done, steps, driver=MIRROR_WRAPPERS)
-        assert a[0].tobytes() == b[0].tobytes() == unroll_expected(rew, done, steps).tobytes() and a[1:] == b[1:]
+        assert a[0].tobytes() == b[0].tobytes() == unroll_expected(rew, done, steps).tobytes() and a[1:] == b[1:] and a[3] == [23, 3, 0, 0]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
