@@ -428,16 +428,26 @@ static_assert(kBlock >= kFoldThreads, "the normalise kernel's prologue needs 256
 __device__ inline double fold_partial_rows(const double* __restrict__ partials, int rows, int cols, double (*red)[kMaxCols], int tid) {
     if (tid < kFoldThreads) {
         const int c = tid & 15, g = tid >> 4;
-        double t[4] = {0, 0, 0, 0};
+        // 16 independent loads in flight per thread: at the <= 256 rows of BASELINE configs[2]'s sizes the whole fold is ONE round
+        // trip to L2 (with 4 in flight it was four, ~3 us of a 6 us kernel at 131,072 envs)
+        constexpr int U = 16;
+        double t[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) t[k] = 0.0;
         if (c < cols) {
             int r = g;
-            for (; r + 3 * 16 < rows; r += 4 * 16) {
+            for (; r + (U - 1) * 16 < rows; r += U * 16) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) t[k] += partials[(int64_t)(r + k * 16) * kMaxCols + c];
+                for (int k = 0; k < U; k++) t[k] += partials[(int64_t)(r + k * 16) * kMaxCols + c];
             }
             for (; r < rows; r += 16) t[0] += partials[(int64_t)r * kMaxCols + c];
         }
-        red[g][c] = (t[0] + t[1]) + (t[2] + t[3]);
+#pragma unroll
+        for (int w = U / 2; w > 0; w >>= 1) {
+#pragma unroll
+            for (int k = 0; k < w; k++) t[k] += t[k + w];
+        }
+        red[g][c] = t[0];
     }
     __syncthreads();
     double s = 0;
