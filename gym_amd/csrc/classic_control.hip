@@ -257,6 +257,17 @@ __device__ inline const float* stats_reader_slot(const StepParams& p) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *p.tick_r = t;      // nobody reads tick_r in this kernel
     return p.stats + 16 * (t & 1);
 }
+// The same, for the hot kernels: the values are read from BOTH slots and picked afterwards, so that the loads do not wait for the
+// tick (one dependent round trip less at the start of a launch-latency-bound kernel).  `idx[k]` are offsets within a slot.
+template <int K> __device__ inline void stats_reader_values(const StepParams& p, const int (&idx)[K], float (&out)[K]) {
+    const int32_t t = *p.tick_w;
+    float a[K], b[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { a[k] = p.stats[idx[k]]; b[k] = p.stats[16 + idx[k]]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p.tick_r = t;
+#pragma unroll
+    for (int k = 0; k < K; k++) out[k] = (t & 1) ? b[k] : a[k];
+}
 
 template <int KIND> struct EnvTraits;
 template <> struct EnvTraits<KIND_CARTPOLE> { static constexpr int F = 4; static constexpr float step_reward = 1.0f; };
@@ -486,10 +497,11 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
     double ep[3] = {0.0, 0.0, 0.0};
     float shift[F + 1];
     if constexpr (NORM) {
-        const float* stats_cur = stats_reader_slot(p);
+        int idx[F + 1];
 #pragma unroll
-        for (int f = 0; f < F; f++) shift[f] = stats_cur[f];
-        shift[F] = stats_cur[2 * F + 1];
+        for (int f = 0; f < F; f++) idx[f] = f;
+        idx[F] = 2 * F + 1;
+        stats_reader_values<F + 1>(p, idx, shift);
     }
     const ActT* actions = (const ActT*)p.actions;
     const StepBuffers& b = p.buf;
@@ -723,11 +735,18 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
     // stream (step / reset / batch-moments) read the slot from tick_w and copied it into tick_r; every block here reads tick_r,
     // block 0 publishes into the OTHER slot and then sets tick_w = tick_r + 1.  Within a kernel nobody reads what that kernel writes.
     const int32_t tick = *q.tick_r;
-    const float* stats_cur = q.stats + 16 * (tick & 1);
+    float st[2 * F + 4];                                     // both slots are read, independently of the tick, and picked afterwards:
+    {                                                        // one dependent round trip less in a kernel that is launch-latency-bound at BASELINE configs[2]'s sizes
+        float s0[2 * F + 4], s1[2 * F + 4];
+#pragma unroll
+        for (int k = 0; k < 2 * F + 4; k++) { s0[k] = q.stats[k]; s1[k] = q.stats[16 + k]; }
+#pragma unroll
+        for (int k = 0; k < 2 * F + 4; k++) st[k] = (tick & 1) ? s1[k] : s0[k];
+    }
     float mean[F], var[F];
 #pragma unroll
-    for (int f = 0; f < F; f++) { mean[f] = stats_cur[f]; var[f] = stats_cur[F + f]; }
-    float ocount = stats_cur[2 * F], rmean = stats_cur[2 * F + 1], rvar = stats_cur[2 * F + 2], rcount = stats_cur[2 * F + 3];
+    for (int f = 0; f < F; f++) { mean[f] = st[f]; var[f] = st[F + f]; }
+    float ocount = st[2 * F], rmean = st[2 * F + 1], rvar = st[2 * F + 2], rcount = st[2 * F + 3];
     // The batch moments: either already reduced (and all-reduced over ranks) in q.moments — the split step — or, for the
     // unsplit single-GPU step, summed here from the step kernel's per-block partial rows by every block redundantly (the rows
     // sit in L2; same function and order as reduce_partials_kernel, so both forms give identical bits).  Saves one launch.
