@@ -158,6 +158,35 @@ def cpu_baseline(seconds_target):
     return out
 
 
+
+def gather_rows(torch, dist, row):
+    """all_gather of a small 1-D host tensor over ranks -> [world, len] host tensor (staged on the device for nccl)."""
+    world = dist.get_world_size()
+    t = row.cuda() if dist.get_backend() == "nccl" else row
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return torch.stack([o.cpu() for o in out])
+
+
+def verify_replicated(torch, dist, reduced_count, local_count, stats_f32):
+    """What a sharded normaliser step must leave behind: the all-reduced batch count is the SUM of the ranks'
+    local env counts, and the replicated running statistics are bit-identical on every rank (every rank applied the same
+    float32 RunningMeanStd::updateFromMoment to the same all-reduced moments, running_mean_std.h:46-66).  Collective: every
+    rank calls it; every rank gets the same verdict.  Returns (ok, reason)."""
+    import numpy as np
+    bits = torch.from_numpy(np.ascontiguousarray(stats_f32, np.float32).view(np.int32).astype(np.int64))
+    row = torch.cat([torch.tensor([int(reduced_count), int(local_count)], dtype=torch.int64), bits])
+    rows = gather_rows(torch, dist, row)
+    total = int(rows[:, 1].sum())
+    for r in range(rows.shape[0]):
+        if int(rows[r, 0]) != total:
+            return False, f"rank {r}: all-reduced batch count {int(rows[r, 0])} != sum of local env counts {total}"
+        if not torch.equal(rows[r, 2:], rows[0, 2:]):
+            k = int((rows[r, 2:] != rows[0, 2:]).nonzero()[0])
+            return False, f"rank {r}: running statistic {k} differs from rank 0's (bits {int(rows[r, 2 + k]):#x} vs {int(rows[0, 2 + k]):#x})"
+    return True, f"{rows.shape[0]} ranks, batch count {total}, {rows.shape[1] - 2} statistics bit-identical"
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # Self-launch: `bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself.
 # ----------------------------------------------------------------------------------------------------------------------
@@ -255,12 +284,46 @@ def main():
             sys.exit(7)
         if os.environ.get("GYM_BENCH_DRY_RUN_HANG_RANK") == os.environ.get("RANK", "0"):   # launcher test hook: this rank never returns
             time.sleep(3600)
-        print(json.dumps({"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
-                          "world": int(os.environ.get("WORLD_SIZE", "1")), "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}), flush=True)
+        verified = None
+        if os.environ.get("GYM_BENCH_DRY_RUN_VERIFY") == "1" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            # launcher test hook: the N>1 self-check (verify_replicated, as measure_config3 runs it) over a real gloo group on the CPU,
+            # with fabricated per-rank results; GYM_BENCH_DRY_RUN_CORRUPT_RANK makes one rank's statistics / batch count wrong
+            import numpy as np
+            import torch
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+            rk, wd = dist.get_rank(), dist.get_world_size()
+            stats = np.arange(8, dtype=np.float32) * 0.25 + 1.0
+            count = 1000 * wd
+            corrupt = os.environ.get("GYM_BENCH_DRY_RUN_CORRUPT_RANK")
+            if corrupt is not None and int(corrupt) == rk:
+                if os.environ.get("GYM_BENCH_DRY_RUN_CORRUPT_WHAT", "stats") == "stats":
+                    stats[3] = np.nextafter(stats[3], np.float32(9))   # one ulp: still a failure
+                else:
+                    count -= 1000                                         # an all-reduce that lost a rank's contribution
+            ok, why = verify_replicated(torch, dist, count, 1000, stats)
+            dist.barrier()
+            dist.destroy_process_group()
+            if not ok:
+                print(f"bench.py: rank {rk}: sharded-normaliser verification FAILED: {why}", file=sys.stderr, flush=True)
+                sys.exit(6)
+            verified = why
+        d = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+             "world": int(os.environ.get("WORLD_SIZE", "1")), "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"}
+        if verified is not None:
+            d["verified"] = verified
+        print(json.dumps(d), flush=True)
         return
     if os.environ.get("GYM_BENCH_TRACE"):   # debugging aid: dump every thread's stack and exit if the run stalls
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["GYM_BENCH_TRACE"]), exit=True)
+
+    # Rank 0's stdout carries exactly ONE line, the JSON record: whatever libraries print on fd 1 (Gloo / RCCL banners, C++ iostreams)
+    # is sent to stderr from here on, and the record is written to the saved descriptor.
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
 
     import numpy as np  # noqa: F401
     import torch
@@ -291,6 +354,7 @@ def main():
         torch.cuda.set_device(0)
         local_rank = 0
     n = args.envs_per_gpu
+    failures = []   # self-checks that did not hold (N > 1 exchange verification): the line still comes out, the exit code is 6
     ranks_seen = dist.get_world_size() if world > 1 else 1
     if ranks_seen != world:
         raise RuntimeError(f"torch.distributed reports {ranks_seen} ranks, the environment says {world}")
@@ -319,14 +383,19 @@ def main():
         dt, kern_ms = time_engine(torch, dist, eng, acts, args.steps, args.warmup, world, PREWARM_TAPE_STEPS if tape_mode else None)
         err = eng.poll_error()
         eps = eng.episode_stats()
+        li = eng.launch_info()
         eng.close()
         del eng, acts
         torch.cuda.empty_cache()
         bps = BYTES_PER_STEP[(env, mode)]
         achieved = bps * n / (kern_ms * 1e-3) / 1e9
+        # residency plan: the 4-B lanes an engine beyond the Infinity Cache keeps IN that cache never reach HBM while
+        # steps run back to back; what HBM itself carries is the rest.  None when the engine does not stream (everything is cached).
+        kept = bin(li["kept_lanes"] & 7).count("1") if li["streams_non_temporally"] else None
         return {
             "value": world * n * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "kernel_ms": kern_ms, "timed_region_s": dt,
             "achieved_gbs": achieved, "bytes_per_env_step": bps, "error_flag": err, "episodes": eps[0],
+            "hbm_only_bytes_per_env_step": None if kept is None else bps - 4 * kept, "launch": li,
         }
 
     def measure_cache_swept(steps=40):
@@ -393,11 +462,37 @@ def main():
         if world > 1:
             dt = max_over_ranks(torch, dist, dt)
         stats = eng.get_norm_stats()
+        out = {}
+        if world > 1:
+            # Self-check of the exchange (no multi-rank RCCL run exists before the 8-GPU box sees this): the all-reduced batch count must be
+            # the sum of the ranks' env counts and the replicated statistics bit-identical on every rank.  A failure fails the run.
+            ok, why = verify_replicated(torch, dist, float(eng.moments[0].item()), n3, stats)
+            out["allreduce_verified"], out["allreduce_check"] = ok, why
+            if not ok:
+                failures.append(f"config 3 at {n3} envs/GPU: {why}")
+            # the collective alone: the engine's own payload (2F+6 doubles), back to back on the step's stream
+            payload = torch.zeros_like(eng.moments)
+            for _ in range(20):
+                allreduce_sum(payload)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 200
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(reps):
+                allreduce_sum(payload)
+            e1.record()
+            torch.cuda.synchronize()
+            out["collective_us"] = round(max_over_ranks(torch, dist, (time.perf_counter() - t0) / reps * 1e6), 2)
+            out["collective_us_gpu_events"] = round(e0.elapsed_time(e1) / reps * 1e3, 2)
         eng.close()
         bps = 16 + 16 + 4 + 8 + 8 + 4 + 4 + (8 + 8 + 4 + 4)   # step kernel 60 B + normalise kernel 24 B
-        return {"value": world * n3 * steps / dt, "unit": "env-steps/s", "envs_per_gpu": n3, "ms_per_step": round(dt / steps * 1e3, 4),
-                "bytes_per_env_step": bps, "achieved_GBs": round(bps * n3 * steps / dt / 1e9, 1), "frac": round(bps * n3 * steps / dt / 1e9 / HBM_PEAK_GBS, 4),
-                "collective": "all_reduce(12 x f64)/step" if world > 1 else None, "obs_count": float(stats[4])}
+        out.update({"value": world * n3 * steps / dt, "unit": "env-steps/s", "envs_per_gpu": n3, "ms_per_step": round(dt / steps * 1e3, 4),
+                    "bytes_per_env_step": bps, "achieved_GBs": round(bps * n3 * steps / dt / 1e9, 1), "frac": round(bps * n3 * steps / dt / 1e9 / HBM_PEAK_GBS, 4),
+                    "collective": f"all_reduce({eng.moments_len} x f64)/step, backend {backend}" if world > 1 else None, "obs_count": float(stats[4])})
+        return out
 
     def measure_config2():
         """BASELINE configs[1]: CartPole N = 65,536, lockstep, tape resets.  (a) one launch per VecEnv::step — 5.5 MB per
@@ -590,7 +685,8 @@ def main():
             return
         printed[0] = True
         line = make_line()
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
 
     def make_line():
         return {
@@ -607,7 +703,15 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(main_m["achieved_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(main_m["achieved_gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "step_kernel", "kernel_ms": round(main_m["kernel_ms"], 4),
-                         "algorithmic_bytes_per_env_step": main_m["bytes_per_env_step"]},
+                         "algorithmic_bytes_per_env_step": main_m["bytes_per_env_step"],
+                         # `frac` is an EFFECTIVE rate: with steps back to back the residency plan serves the kept 4-B lanes from the
+                         # Infinity Cache.  frac_hbm_only prices only what HBM itself carries; frac_cache_swept is the same kernel
+                         # timed with a 512 MiB sweep of that cache between every two steps (what a policy network does).
+                         "hbm_only_bytes_per_env_step": main_m["hbm_only_bytes_per_env_step"],
+                         "frac_hbm_only": None if main_m["hbm_only_bytes_per_env_step"] is None else
+                         round(main_m["achieved_gbs"] * main_m["hbm_only_bytes_per_env_step"] / main_m["bytes_per_env_step"] / HBM_PEAK_GBS, 4),
+                         "frac_cache_swept": (extra.get("cartpole_lockstep_cache_swept_between_steps") or {}).get("frac"),
+                         "kept_lanes": main_m["launch"]["kept_lanes"], "grid": main_m["launch"]["grid"]},
             "cpu_baseline": cpu,
             "extra": extra,
         }
@@ -659,7 +763,8 @@ def main():
         if rank == 0 and world == 1:
             guarded("pcie_inclusive_never_value", measure_pcie_inclusive, 10)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    dog.cancel()   # the other ranks wait at the barrier below while rank 0 times the CPU baseline
+    if rank == 0 and not args.no_cpu_baseline:   # any world: no SCALE line carries a null baseline
         in_flight[0] = "cpu_baseline"
         try:
             c = cpu_baseline(args.cpu_seconds)
@@ -674,7 +779,8 @@ def main():
         except Exception as e:  # noqa: BLE001
             cpu = {"error": f"{type(e).__name__}: {e}"}
 
-    dog.cancel()
+    if failures:
+        extra["error"] = "; ".join(failures)
     emit()
     if world > 1:
         try:
@@ -682,6 +788,9 @@ def main():
             dist.destroy_process_group()
         except Exception:  # noqa: BLE001
             pass
+    if failures:
+        print(f"bench.py: rank {rank}: " + "; ".join(failures), file=sys.stderr, flush=True)
+        sys.exit(6)
 
 
 if __name__ == "__main__":

@@ -48,3 +48,22 @@ def test_failing_rank_makes_the_launch_fail():
 def test_hung_rank_hits_the_launch_timeout():
     r = _run(["--gpus", "2", "--launch-dry-run"], {"GYM_BENCH_DRY_RUN_HANG_RANK": "1", "GYM_BENCH_LAUNCH_TIMEOUT": "2"})
     assert r.returncode == 4 and "timed out" in r.stderr
+
+
+# ---- the N > 1 self-check (bench.py verify_replicated, what measure_config3 runs after its timed loop) over a real gloo group ----
+def test_sharded_verification_passes_on_consistent_ranks():
+    r = _run(["--gpus", "2", "--launch-dry-run"], {"GYM_BENCH_DRY_RUN_VERIFY": "1"}, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["ok"] and all("2 ranks, batch count 2000" in x["verified"] for x in d["ranks"])
+
+
+@pytest.mark.parametrize("what", ["stats", "count"])
+def test_a_rank_whose_verification_fails_makes_the_launch_fail(what):
+    # one rank's replicated statistics differ by one ulp / the all-reduced batch count lost a rank's contribution:
+    # every rank sees the same gathered table, reports the failure and exits 6; the launcher relays that code
+    r = _run(["--gpus", "2", "--launch-dry-run"], {"GYM_BENCH_DRY_RUN_VERIFY": "1", "GYM_BENCH_DRY_RUN_CORRUPT_RANK": "1",
+                                                    "GYM_BENCH_DRY_RUN_CORRUPT_WHAT": what}, timeout=300)
+    assert r.returncode == 6, (r.returncode, r.stderr[-2000:])
+    assert "verification FAILED" in r.stderr
+    assert ("running statistic 3 differs" in r.stderr) if what == "stats" else ("all-reduced batch count" in r.stderr)
