@@ -267,8 +267,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=16 * 1024 * 1024)
     ap.add_argument("--env", default="cartpole", choices=["cartpole", "mountaincar"])
     ap.add_argument("--mode", default="lockstep", choices=["lockstep", "f32"])
-    ap.add_argument("--reset-mode", default="rng", choices=["tape", "rng"],
-                    help="CartPole reset source: in-kernel counter RNG (SURVEY.md §8d config 5) or a device-resident reset tape (the form host-drawn mt19937 resets take)")
+    ap.add_argument("--reset-mode", default="rng", choices=["tape", "rng", "mt19937"],
+                    help="CartPole reset source: in-kernel counter RNG (SURVEY.md §8d config 5), a device-resident reset tape (the form host-drawn "
+                         "mt19937 resets take), or per-env std::mt19937 generators on the device (the reference's own streams, for ever)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (f32 / MountainCar) measurements")
@@ -364,10 +365,14 @@ def main():
         reset_mode = reset_mode or args.reset_mode
         kind = L.ENV_CARTPOLE if env == "cartpole" else L.ENV_MOUNTAINCAR
         wrappers = L.WRAP_TIME_LIMIT | L.WRAP_MONITOR | (L.WRAP_CLIP_REWARD if env == "mountaincar" else 0)
+        rm = L.RESET_COUNTER_RNG
+        if env == "cartpole" and reset_mode in ("tape", "mt19937"):
+            rm = L.RESET_TAPE if reset_mode == "tape" else L.RESET_MT19937
         cfg = EngineConfig(env_kind=kind, n_envs=n, precision=L.PRECISION_LOCKSTEP_F64 if mode == "lockstep" else L.PRECISION_F32,
-                           reset_mode=L.RESET_TAPE if (env == "cartpole" and reset_mode == "tape") else L.RESET_COUNTER_RNG, wrappers=wrappers,
-                           max_episode_steps=500 if env == "cartpole" else 200, env_offset=rank * n, seed=0)
+                           reset_mode=rm, wrappers=wrappers, max_episode_steps=500 if env == "cartpole" else 200, env_offset=rank * n, seed=0)
         eng = Engine(cfg, local_rank)
+        if rm == L.RESET_MT19937:
+            eng.seed(0)   # VecEnv::seed(0): env i <- std::mt19937(0 + global index), seeded on the device
         if env == "cartpole" and reset_mode == "tape":
             # reset tape rows: every episode lasts >= 8 steps, so (W+K)/8 + 2 rows can never run out
             eng.generate_reset_tape((args.steps + args.warmup + PREWARM_TAPE_STEPS) // 8 + 2)
@@ -377,10 +382,11 @@ def main():
         acts = [torch.randint(0, n_act, (n,), dtype=torch.int32, device="cuda", generator=g) for _ in range(4)]
         return eng, acts
 
-    def measure(env, mode, reset_mode=None):
+    def measure(env, mode, reset_mode=None, steps=None):
         eng, acts = build(env, mode, reset_mode)
         tape_mode = env == "cartpole" and (reset_mode or args.reset_mode) == "tape"
-        dt, kern_ms = time_engine(torch, dist, eng, acts, args.steps, args.warmup, world, PREWARM_TAPE_STEPS if tape_mode else None)
+        steps = steps or args.steps
+        dt, kern_ms = time_engine(torch, dist, eng, acts, steps, args.warmup, world, PREWARM_TAPE_STEPS if tape_mode else None)
         err = eng.poll_error()
         eps = eng.episode_stats()
         li = eng.launch_info()
@@ -393,7 +399,7 @@ def main():
         # steps run back to back; what HBM itself carries is the rest.  None when the engine does not stream (everything is cached).
         kept = bin(li["kept_lanes"] & 7).count("1") if li["streams_non_temporally"] else None
         return {
-            "value": world * n * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "kernel_ms": kern_ms, "timed_region_s": dt,
+            "value": world * n * steps / dt, "ms_per_step": dt / steps * 1e3, "kernel_ms": kern_ms, "timed_region_s": dt, "steps": steps,
             "achieved_gbs": achieved, "bytes_per_env_step": bps, "error_flag": err, "episodes": eps[0],
             "hbm_only_bytes_per_env_step": None if kept is None else bps - 4 * kept, "launch": li,
         }
@@ -740,11 +746,19 @@ def main():
         except Exception as e:  # noqa: BLE001 — report, never lose the headline line
             extra[key] = {"error": f"{type(e).__name__}: {e}"}
 
-    def classic(env, mode, reset_mode=None):
-        m = measure(env, mode, reset_mode)
-        return {"value": m["value"], "unit": "env-steps/s", "kernel_ms": round(m["kernel_ms"], 4),
+    def classic(env, mode, reset_mode=None, steps=None):
+        m = measure(env, mode, reset_mode, steps)
+        return {"value": m["value"], "unit": "env-steps/s", "kernel_ms": round(m["kernel_ms"], 4), "steps": m["steps"],
                 "bytes_per_env_step": m["bytes_per_env_step"], "achieved_GBs": round(m["achieved_gbs"], 1),
-                "frac": round(m["achieved_gbs"] / HBM_PEAK_GBS, 4)}
+                "frac": round(m["achieved_gbs"] / HBM_PEAK_GBS, 4), "error_flag": m["error_flag"]}
+
+    def mt19937_resets():
+        """The reference-exact reset source at scale: per-env std::mt19937 states on the device (GYMHIP_RESET_MT19937).  An env's
+        624-word generator block is regenerated once per 156 of its episodes (~3,500 random-policy steps), so the timed region is long
+        enough to hold a whole period: every env regenerates at least once inside it."""
+        out = classic("cartpole", "lockstep", "mt19937", steps=max(args.steps, 4000))
+        out["note"] = "reset states = std::mt19937(seed + env index) per env, seeded / twisted / tempered on the GPU; bit-identical to a host-drawn tape (tests/test_gpu_mt19937.py)"
+        return out
 
     if not args.no_extra and args.env == "cartpole" and args.mode == "lockstep":
         other = "tape" if args.reset_mode == "rng" else "rng"
@@ -752,6 +766,7 @@ def main():
         for env, mode in (("cartpole", "f32"), ("mountaincar", "lockstep"), ("mountaincar", "f32")):
             guarded(f"{env}_{mode}", classic, env, mode)
         guarded(f"cartpole_f32_{other}_resets", classic, "cartpole", "f32", other)
+        guarded("cartpole_lockstep_mt19937_resets", mt19937_resets)
         guarded("cartpole_lockstep_cache_swept_between_steps", measure_cache_swept)
         guarded("config2_cartpole_lockstep_65536", measure_config2)
         guarded("cartpole_lockstep_rollout_32_steps_per_launch", measure_rollout_big)

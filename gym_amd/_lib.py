@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("GYMHIP_LIB") or os.path.join(_HERE, "lib", "libgymhip
 OK = 0
 ENV_CARTPOLE, ENV_MOUNTAINCAR = 0, 1
 PRECISION_LOCKSTEP_F64, PRECISION_F32 = 0, 1
-RESET_TAPE, RESET_COUNTER_RNG = 0, 1
+RESET_TAPE, RESET_COUNTER_RNG, RESET_MT19937 = 0, 1, 2
 WRAP_TIME_LIMIT, WRAP_CLIP_REWARD, WRAP_MONITOR = 1, 2, 4
 WRAP_NORM_OBS, WRAP_NORM_REWARD, WRAP_NORM_TRAINING = 8, 16, 32
 WRAP_NO_AUTO_RESET = 64
@@ -59,6 +59,7 @@ class Buffers(C.Structure):
         ("norm_stats", C.c_void_p),
         ("moments", C.c_void_p),
         ("episode_totals", C.c_void_p),
+        ("mt_state", C.c_void_p),
     ]
 
 

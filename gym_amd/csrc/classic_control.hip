@@ -90,6 +90,129 @@ __host__ __device__ inline void counter_reset_draw(uint64_t seed, int64_t global
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// MT19937 reset mode: every env owns the state array of a std::mt19937 ON THE DEVICE (u32 [N][624], 2,496 B per env) — the
+// reference's own generator (env.h:83, cartpole.cpp:21-26), continued for ever, with no host refill and no PCIe traffic.  The k-th
+// reset of an env takes outputs 4k .. 4k+3 of its stream: "row" k % 156 of the current 624-word block; when a reset needs row 0
+// the block is regenerated first, in place, exactly as libstdc++'s mersenne_twister_engine::_M_gen_rand does when _M_p reaches
+// 624 (a freshly seeded engine starts there, so the first reset twists too).  The array holds the UNTEMPERED words; a row is
+// tempered when read.  The twist is done by the whole WAVE for one env at a time: its 64 lanes stream the env's 624 words through
+// LDS with coalesced loads and stores, so the regeneration (one per 156 resets of an env) moves 2 x 2,496 B at full line efficiency
+// and costs the other lanes about a microsecond, instead of one lane walking 624 words alone.
+// Integer arithmetic throughout: the device stream is bit-identical to std::mt19937's (tests/test_gpu_mt19937.py pins it against
+// libstdc++ on the host).
+// ------------------------------------------------------------------------------------------------------------
+using u32x4 = uint32_t __attribute__((ext_vector_type(4)));
+constexpr int kMtWords = 624, kMtShift = 397, kMtRows = kMtWords / 4;
+constexpr uint32_t kMtCursorPeriod = 6720u * (uint32_t)kMtRows;   // 1,048,320: the largest multiple of 156 the 20-bit cursor field holds
+__host__ __device__ inline uint32_t mt_temper(uint32_t y) {        // mersenne_twister_engine::operator() (u = 11, s = 7, t = 15, l = 18)
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9D2C5680u;
+    y ^= (y << 15) & 0xEFC60000u;
+    y ^= y >> 18;
+    return y;
+}
+__host__ __device__ inline uint32_t mt_mix(uint32_t cur, uint32_t nxt, uint32_t far) {
+    const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7FFFFFFFu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+}
+__device__ inline void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// Collective over the ACTIVE lanes of a wave (call it from converged code).  A lane with `want` gets the four raw (tempered)
+// outputs of its env's next reset row in `raw`; `cursor` = rows its env has consumed so far (mod kMtCursorPeriod).
+// `lds` = this wave's private 624-word scratch.
+template <bool SAME_LAUNCH_WRITES = false>   // true (rollout kernel): an env's block may have been rewritten earlier in this launch, by other lanes
+__device__ inline void mt_draw_row(bool want, uint32_t cursor, uint32_t* __restrict__ mt_state, int64_t i, uint32_t* lds, uint32_t (&raw)[4]) {
+    const uint32_t pos = cursor % (uint32_t)kMtRows;
+    const bool twist = want && pos == 0;
+    const uint64_t active = __ballot(1);
+    uint64_t todo = __ballot(twist);
+    if (todo) {                                                   // wave-uniform
+        const int lane = (int)__lane_id();
+        const int nact = __popcll(active);
+        const int rank = __popcll(active & ((1ull << lane) - 1ull));
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int64_t ei = ((int64_t)__shfl((int)(i >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)i, src);
+            uint32_t* st = mt_state + ei * kMtWords;
+            // Rounds of `nact` consecutive words in increasing order; within a round every lane reads its three operands before any
+            // lane writes.  That reproduces the sequential recurrence: x[k+1] is still old when x[k] is computed, and the far operand
+            // x[(k+397) % 624] is old for k < 227 and already new (written >= 227 words, i.e. >= 3 rounds, earlier) for k >= 227.
+            auto round = [&](int k) {
+                uint32_t v = 0;
+                if (k < kMtWords) {
+                    const int k1 = k + 1 == kMtWords ? 0 : k + 1;
+                    const int kf = k + kMtShift >= kMtWords ? k + kMtShift - kMtWords : k + kMtShift;
+                    v = mt_mix(lds[k], lds[k1], lds[kf]);
+                }
+                wave_lds_fence();
+                if (k < kMtWords) lds[k] = v;
+                wave_lds_fence();
+            };
+            if (nact == 64) {
+                // the full wave (all but a launch's last wave): everything unrolled, the ten 256-B loads of the block issued back to back
+                // (ONE round trip to HBM instead of ten), non-temporal both ways — a block is touched once per ~3,500 steps
+                constexpr int R = (kMtWords + 63) / 64;
+                uint32_t w[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) { const int k = lane + 64 * r; w[r] = k < kMtWords ? __builtin_nontemporal_load(st + k) : 0u; }
+#pragma unroll
+                for (int r = 0; r < R; r++) { const int k = lane + 64 * r; if (k < kMtWords) lds[k] = w[r]; }
+                wave_lds_fence();
+#pragma unroll
+                for (int r = 0; r < R; r++) round(lane + 64 * r);
+#pragma unroll
+                for (int r = 0; r < R; r++) { const int k = lane + 64 * r; if (k < kMtWords) __builtin_nontemporal_store(lds[k], st + k); }
+            } else {
+                for (int k = rank; k < kMtWords; k += nact) lds[k] = st[k];
+                wave_lds_fence();
+                for (int base = 0; base < kMtWords; base += nact) round(base + rank);
+                for (int k = rank; k < kMtWords; k += nact) st[k] = lds[k];
+            }
+            if (lane == src) { raw[0] = mt_temper(lds[0]); raw[1] = mt_temper(lds[1]); raw[2] = mt_temper(lds[2]); raw[3] = mt_temper(lds[3]); }
+            // rollout kernel: the block's later rows are read back in this launch (by the env's own lane, past L1): the stores must have
+            // reached L2 by then — wait for them here (vmcnt = 0) rather than paying a device-scope fence
+            if constexpr (SAME_LAUNCH_WRITES) __builtin_amdgcn_s_waitcnt(0);
+            wave_lds_fence();
+        }
+    }
+    if (want && !twist) {
+        const uint32_t* row = mt_state + i * kMtWords + pos * 4u;
+        if constexpr (SAME_LAUNCH_WRITES) {   // L1-bypassing loads: the wave's own earlier stores (made by other lanes) must be seen
+#pragma unroll
+            for (int k = 0; k < 4; k++) raw[k] = mt_temper(__hip_atomic_load(row + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        } else {                              // one 16-B gather per reset, as from a tape; this launch never wrote the block
+            const u32x4 v = *(const u32x4*)row;
+            raw[0] = mt_temper(v.x); raw[1] = mt_temper(v.y); raw[2] = mt_temper(v.z); raw[3] = mt_temper(v.w);
+        }
+    }
+}
+
+// std::mt19937::seed(value) (libstdc++ bits/random.tcc): x[0] = value mod 2^32, x[k] = 1812433253 (x[k-1] ^ x[k-1] >> 30) + k; the
+// engine then stands at _M_p = 624.  env i <- seed + env_offset + i (sync_env.h:74-83), or the default-constructed 5489 (env.h:83).
+// One env per lane runs the serial recurrence; 64-word chunks go through an LDS tile so that the stores are 256-B coalesced.
+__global__ __launch_bounds__(256) void mt_seed_kernel(uint32_t* __restrict__ mt_state, int64_t n, int seeded, uint64_t seed, int64_t env_offset) {
+    __shared__ uint32_t tile[4][64][65];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64; base < n; base += (int64_t)gridDim.x * 256) {
+        const int64_t i = base + lane;
+        uint32_t x = seeded ? (uint32_t)(seed + (uint64_t)(env_offset + i)) : 5489u;
+        for (int c = 0; c < kMtWords; c += 64) {
+            const int cnt = kMtWords - c < 64 ? kMtWords - c : 64;
+            for (int j = 0; j < cnt; j++) {
+                const uint32_t k = (uint32_t)(c + j);
+                if (k > 0) x = 1812433253u * (x ^ (x >> 30)) + k;
+                tile[wave][lane][j] = x;
+            }
+            wave_lds_fence();
+            for (int e = 0; e < 64 && base + e < n; e++)
+                if (lane < cnt) mt_state[(base + e) * kMtWords + c + lane] = tile[wave][e][lane];
+            wave_lds_fence();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Dynamics.  State held as T[F] in registers.
 // ------------------------------------------------------------------------------------------------------------
 struct CartPoleC {  // cartpole.h:30-39 — float constants
@@ -244,7 +367,15 @@ template <int KIND> struct CounterWord {
         if (c >= kCursorMask) { atomicOr(error_flag, 2); return 0; }   // cursor field exhausted (2^20 episodes per env)
         return c + 1;
     }
-    __host__ __device__ static uint32_t next_cursor_wrapping(uint32_t c) { return (c + 1u) & kCursorMask; }   // COUNTER_RNG: an episode index, free to wrap
+    // COUNTER_RNG: the field is the env's episode index and wraps after 2^20 episodes — from there on the env's reset states repeat
+    // with that period (documented in gymhip.h); the wrap is reported once, as information, in bit 4 of the error word
+    __device__ static uint32_t next_cursor_wrapping(uint32_t c, int32_t* error_flag) {
+        const uint32_t nx = (c + 1u) & kCursorMask;
+        if (nx == 0u) atomicOr(error_flag, 16);
+        return nx;
+    }
+    // MT19937: rows consumed mod kMtCursorPeriod (a multiple of the 156 rows of a generator block): the stream itself never ends
+    __host__ __device__ static uint32_t next_cursor_mt(uint32_t c) { return c + 1u == kMtCursorPeriod ? 0u : c + 1u; }
     __host__ __device__ static uint32_t pack(int t, uint32_t cur, bool done, bool trunc) {
         return (done ? 0x80000000u : 0u) | (trunc ? 0x40000000u : 0u) | (cur << S) | (uint32_t)t;
     }
@@ -361,26 +492,48 @@ template <int F, bool NT = kNtDefault> __device__ inline void store_state(const 
     store_i32<NT>((int32_t*)b.state, i, k);
 }
 
-// Reset state of env i for episode `ep` (already range-checked).
+// Reset state of env i for episode `ep` (already range-checked).  `rs` is the engine's reset source, read from device memory by the
+// calling kernel (so a recorded launch follows re-seeds and tape replacements).
 template <int KIND, typename T>
-__device__ inline void reset_state(const StepParams& p, int64_t i, int64_t ep, T (&s)[EnvTraits<KIND>::F]) {
+__device__ inline void reset_state(const StepParams& p, const ResetSource& rs, int64_t i, int64_t ep, T (&s)[EnvTraits<KIND>::F]) {
     if constexpr (KIND == KIND_CARTPOLE) {
         float r[4];
         if (p.reset_mode == GYMHIP_RESET_TAPE) {
 #if GYMHIP_TAPE_NT
-            f32x4 v = __builtin_nontemporal_load((const f32x4*)p.tape + (ep * p.n + i));   // each row is read once: do not keep its line
+            f32x4 v = __builtin_nontemporal_load((const f32x4*)rs.tape + (ep * p.n + i));   // each row is read once: do not keep its line
 #else
-            f32x4 v = ((const f32x4*)p.tape)[ep * p.n + i];
+            f32x4 v = ((const f32x4*)rs.tape)[ep * p.n + i];
 #endif
             r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
         } else {
-            counter_reset_draw(p.seed, p.env_offset + i, ep, r);
+            counter_reset_draw(rs.seed, p.env_offset + i, ep, r);
         }
 #pragma unroll
         for (int f = 0; f < 4; f++) s[f] = (T)r[f];  // float widened into the double state (cartpole.cpp:23-26)
     } else {
         s[0] = (T)-0.5; s[1] = (T)0.0;  // mountain_car.cpp:38-42
     }
+}
+// MT19937 mode: the four raw generator outputs of the env's reset row (mt_draw_row) through libstdc++'s
+// uniform_real_distribution<float>(-0.05f, 0.05f) arithmetic (cartpole.cpp:21-26).
+template <typename T> __device__ inline void reset_state_mt(const uint32_t (&raw)[4], T (&s)[4]) {
+#pragma unroll
+    for (int f = 0; f < 4; f++) s[f] = (T)canonical_to_range(raw[f]);
+}
+// The env's new episode: picks the reset source's row for `cursor`, advances the cursor, writes the state.  TAPE / COUNTER_RNG /
+// MountainCar only (MT engines: mt_draw_row + reset_state_mt).
+template <int KIND, typename T>
+__device__ inline void begin_episode(const StepParams& p, const ResetSource& rs, int64_t i, uint32_t& cursor, T (&s)[EnvTraits<KIND>::F]) {
+    int64_t e = cursor;
+    if (KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE) {
+        if (e >= rs.tape_episodes) { atomicOr(p.error_flag, 1); e = e % rs.tape_episodes; }
+        cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
+    } else if (KIND == KIND_CARTPOLE) {
+        // stateless: (seed, env, the env's episode index) keys the draw; no host-side step counter, so a recorded step replays
+        // correctly from a HIP graph
+        cursor = CounterWord<KIND>::next_cursor_wrapping(cursor, p.error_flag);
+    }
+    reset_state<KIND, T>(p, rs, i, e, s);
 }
 
 // Block reduction of per-thread double columns in a fixed order (deterministic), through LDS: every thread parks its COLS
@@ -483,12 +636,16 @@ __global__ __launch_bounds__(kFoldThreads) void reduce_partials_kernel(const dou
 // ------------------------------------------------------------------------------------------------------------
 // Kernel A: one VecEnv::step for every env.
 // ------------------------------------------------------------------------------------------------------------
-template <int KIND, bool LOCKSTEP, typename ActT, bool NORM, bool NT, int KEEP>   // KEEP: the 4-B lanes an NT kernel keeps in the Infinity Cache (one of kPlans)
+template <int KIND, bool LOCKSTEP, typename ActT, bool NORM, bool NT, int KEEP, bool MT = false>   // KEEP: the 4-B lanes an NT kernel keeps in the Infinity Cache (one of kPlans); MT: per-env std::mt19937 resets
 #ifndef GYMHIP_STEP_WAVES
 #define GYMHIP_STEP_WAVES 1   // experiment knob: min waves per SIMD the step kernel is compiled for (caps its VGPRs)
 #endif
 __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const StepParams p) {
+    static_assert(!MT || KIND == KIND_CARTPOLE, "only CartPole draws its reset state");
     constexpr int F = EnvTraits<KIND>::F;
+    __shared__ uint32_t mt_lds[MT ? kBlock / 64 : 1][MT ? kMtWords : 1];   // one generator block per wave (mt_draw_row)
+    ResetSource rs{};
+    if constexpr (KIND == KIND_CARTPOLE && !MT) rs = *p.src;   // uniform, issued with the first loads; only the reset path uses it
     using T = typename std::conditional<LOCKSTEP, double, float>::type;
     constexpr int NCOL = NORM ? 2 * F + 2 : 1;
     double acc[NCOL];
@@ -507,7 +664,6 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
     const StepBuffers& b = p.buf;
     const bool time_limit = p.wrappers & GYMHIP_WRAP_TIME_LIMIT;
     const bool clip = p.wrappers & GYMHIP_WRAP_CLIP_REWARD;
-    const bool tape_mode = KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE;
     const bool ret_lane = (p.wrappers & GYMHIP_WRAP_NORM_REWARD) && (p.wrappers & GYMHIP_WRAP_NORM_TRAINING);
     const bool auto_reset = !(p.wrappers & GYMHIP_WRAP_NO_AUTO_RESET);   // sync_env.h:28,92
 
@@ -576,6 +732,8 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
         if (clip) reward = reward == 0.f ? reward : (reward > 0.f ? 1.f : -1.f);           // clip_reward.h:22-24
         if (frozen) { atomicOr(p.error_flag, 8); t = CounterWord<KIND>::steps_field(w); done = true; trunc = (w >> 30) & 1u; reward = 0.f; }
 
+        uint32_t mt_raw[4];
+        if constexpr (MT) mt_draw_row(done && !frozen && auto_reset, cursor, p.mt_state, i, mt_lds[threadIdx.x >> 6], mt_raw);   // wave-collective
         if (done && !frozen) {
             // Monitor (monitor.h:78-97): every step of these envs pays the same reward, so the ordered float sum
             // of t copies equals float(t)*reward exactly (t < 2^24).  The finished episode's (length, truncated)
@@ -583,16 +741,8 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
             // HBM traffic and no scattered read-modify-write on the done path.
             ep[0] += 1.0; ep[1] += (double)((float)t * reward); ep[2] += (double)t;
             if (auto_reset) {                  // sync_env.h:92-100: terminal obs replaced by the reset obs (else: kept, no draw consumed)
-                int64_t e;
-                if (tape_mode) {
-                    e = cursor;
-                    if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
-                    cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
-                } else {
-                    e = cursor;                // stateless: (seed, env, the env's episode index) keys the draw; no host-side step counter,
-                    cursor = CounterWord<KIND>::next_cursor_wrapping(cursor);   // so a recorded step replays correctly from a HIP graph
-                }
-                reset_state<KIND, T>(p, i, e, s);
+                if constexpr (MT) { reset_state_mt<T>(mt_raw, s); cursor = CounterWord<KIND>::next_cursor_mt(cursor); }
+                else begin_episode<KIND, T>(p, rs, i, cursor, s);
             }
         }
 
@@ -641,10 +791,13 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
 // VecEnv::reset(): every env starts a new episode.  In TAPE mode env i takes the tape row at its own cursor and advances it —
 // a CartPoleEnv's generator keeps running across resets (cartpole.cpp:21-26), so a second reset() draws the NEXT four
 // values, not the first four again.  A fresh workspace (or a freshly drawn tape) has every cursor at 0.
-template <int KIND, bool LOCKSTEP, bool NORM>
+template <int KIND, bool LOCKSTEP, bool NORM, bool MT = false>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const StepParams p) {
     constexpr int F = EnvTraits<KIND>::F;
     using T = typename std::conditional<LOCKSTEP, double, float>::type;
+    __shared__ uint32_t mt_lds[MT ? kBlock / 64 : 1][MT ? kMtWords : 1];
+    ResetSource rs{};
+    if constexpr (KIND == KIND_CARTPOLE && !MT) rs = *p.src;
     constexpr int NCOL = NORM ? 2 * F + 2 : 1;
     double acc[NCOL];
 #pragma unroll
@@ -659,18 +812,15 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepParams p) {
     for (int64_t i = (int)threadIdx.x < p.lanes ? (int64_t)blockIdx.x * p.lanes + threadIdx.x : p.n; i < p.n; i += (int64_t)gridDim.x * p.lanes) {
         T s[F];
         uint32_t cursor = 0;
-        int64_t e = 0;
-        if constexpr (KIND == KIND_CARTPOLE) {   // the env's episode index: the tape row, or the counter-RNG key
-            cursor = CounterWord<KIND>::cursor(b.counter[i]);
-            e = cursor;
-            if (p.reset_mode == GYMHIP_RESET_TAPE) {
-                if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
-                cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
-            } else {
-                cursor = CounterWord<KIND>::next_cursor_wrapping(cursor);
-            }
+        if constexpr (KIND == KIND_CARTPOLE) cursor = CounterWord<KIND>::cursor(b.counter[i]);   // the env's episode index: the tape row, the generator row or the counter-RNG key
+        if constexpr (MT) {
+            uint32_t mt_raw[4];
+            mt_draw_row(true, cursor, p.mt_state, i, mt_lds[threadIdx.x >> 6], mt_raw);   // wave-collective (the loop body is converged)
+            reset_state_mt<T>(mt_raw, s);
+            cursor = CounterWord<KIND>::next_cursor_mt(cursor);
+        } else {
+            begin_episode<KIND, T>(p, rs, i, cursor, s);
         }
-        reset_state<KIND, T>(p, i, e, s);
         float o[F];
 #pragma unroll
         for (int f = 0; f < F; f++) o[f] = (float)s[f];
@@ -831,23 +981,28 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
 // VecEnv::reset(int index) (sync_env.h:128-139) under VecNormalize::reset(int index) (vec_normalize.h:179-189): one env is
 // reset, its return lane cleared, and its observation normalised with the CURRENT statistics (no RMS update).  Monitor
 // allows early resets (monitor.h:49, allowEarlyResets): the unfinished episode is dropped without a record.
-template <int KIND, bool LOCKSTEP>
-__global__ void reset_index_kernel(const StepParams p, int64_t i, float* obs_norm, float clip_obs, float epsilon) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+template <int KIND, bool LOCKSTEP, bool MT = false>
+__global__ __launch_bounds__(64) void reset_index_kernel(const StepParams p, int64_t i, float* obs_norm, float clip_obs, float epsilon) {
     constexpr int F = EnvTraits<KIND>::F;
     using T = typename std::conditional<LOCKSTEP, double, float>::type;
     const StepBuffers& b = p.buf;
-    const bool tape_mode = KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE;
+    __shared__ uint32_t mt_lds[MT ? kMtWords : 1];
+    const bool owner = blockIdx.x == 0 && threadIdx.x == 0;
     uint32_t cursor = CounterWord<KIND>::cursor(b.counter[i]);
-    int64_t e = cursor;
-    if (tape_mode) {
-        if (e >= p.tape_episodes) { atomicOr(p.error_flag, 1); e = e % p.tape_episodes; }
-        cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
-    } else if (KIND == KIND_CARTPOLE) {
-        cursor = CounterWord<KIND>::next_cursor_wrapping(cursor);
-    }
     T s[F];
-    reset_state<KIND, T>(p, i, e, s);
+    if constexpr (MT) {
+        if (blockIdx.x != 0) return;
+        uint32_t mt_raw[4];
+        mt_draw_row(owner, cursor, p.mt_state, i, mt_lds, mt_raw);   // the whole wave helps when the env's generator block has to be regenerated
+        if (!owner) return;
+        reset_state_mt<T>(mt_raw, s);
+        cursor = CounterWord<KIND>::next_cursor_mt(cursor);
+    } else {
+        if (!owner) return;
+        ResetSource rs{};
+        if constexpr (KIND == KIND_CARTPOLE) rs = *p.src;
+        begin_episode<KIND, T>(p, rs, i, cursor, s);
+    }
     float o[F];
 #pragma unroll
     for (int f = 0; f < F; f++) o[f] = (float)s[f];
@@ -883,7 +1038,7 @@ __global__ __launch_bounds__(kBlock) void batch_moments_kernel(const float* __re
 }
 
 // K steps in one launch; state lives in registers between steps.
-template <int KIND, bool LOCKSTEP>
+template <int KIND, bool LOCKSTEP, bool MT = false>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepParams p, const uint8_t* __restrict__ tape, int64_t K,
                                                           uint8_t* rec_done, float* rec_reward, uint8_t* rec_trunc, float* rec_obs) {
     constexpr int F = EnvTraits<KIND>::F;
@@ -891,7 +1046,9 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepParams p, con
     const StepBuffers& b = p.buf;
     const bool time_limit = p.wrappers & GYMHIP_WRAP_TIME_LIMIT;
     const bool clip = p.wrappers & GYMHIP_WRAP_CLIP_REWARD;
-    const bool tape_mode = KIND == KIND_CARTPOLE && p.reset_mode == GYMHIP_RESET_TAPE;
+    __shared__ uint32_t mt_lds[MT ? kBlock / 64 : 1][MT ? kMtWords : 1];
+    ResetSource rs{};
+    if constexpr (KIND == KIND_CARTPOLE && !MT) rs = *p.src;
     double ep[3] = {0.0, 0.0, 0.0};
     for (int64_t i = (int)threadIdx.x < p.lanes ? (int64_t)blockIdx.x * p.lanes + threadIdx.x : p.n; i < p.n; i += (int64_t)gridDim.x * p.lanes) {
         T s[F];
@@ -917,18 +1074,12 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const StepParams p, con
             if (time_limit && t >= p.max_episode_steps) { trunc = !env_done; done = true; }
             reward = EnvTraits<KIND>::step_reward;
             if (clip) reward = reward == 0.f ? reward : (reward > 0.f ? 1.f : -1.f);
+            uint32_t mt_raw[4];
+            if constexpr (MT) mt_draw_row<true>(done, cursor, p.mt_state, i, mt_lds[threadIdx.x >> 6], mt_raw);   // wave-collective: every lane of the wave runs the same K steps
             if (done) {
                 ep[0] += 1.0; ep[1] += (double)((float)t * reward); ep[2] += (double)t;
-                int64_t er;
-                if (tape_mode) {
-                    er = cursor;
-                    if (er >= p.tape_episodes) { atomicOr(p.error_flag, 1); er = er % p.tape_episodes; }
-                    cursor = CounterWord<KIND>::next_cursor(cursor, p.error_flag);
-                } else {
-                    er = cursor;
-                    cursor = CounterWord<KIND>::next_cursor_wrapping(cursor);
-                }
-                reset_state<KIND, T>(p, i, er, s);
+                if constexpr (MT) { reset_state_mt<T>(mt_raw, s); cursor = CounterWord<KIND>::next_cursor_mt(cursor); }
+                else begin_episode<KIND, T>(p, rs, i, cursor, s);
             }
             rec = CounterWord<KIND>::pack(t, cursor, done, trunc);
             if (done) t = 0;
@@ -1042,7 +1193,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
     size_t state, obs, obs_norm, reward, done, counter, returns;
-    size_t stats /*3 slots*/, ticks /*tick_w, tick_r*/, moments, partials, ep_partials, ep_totals, ep_totals_global, error_flag, cursor_max, total;
+    size_t stats /*3 slots*/, ticks /*tick_w, tick_r*/, moments, partials, ep_partials, ep_totals, ep_totals_global, error_flag, cursor_max, reset_source, mt_state, total;
 };
 
 int obs_dim_of(int kind) { return kind == KIND_CARTPOLE ? 4 : 2; }
@@ -1051,7 +1202,7 @@ bool valid_config(const gymhip_config* c) {
     if (!c || c->struct_size != (int32_t)sizeof(gymhip_config)) return false;
     if (c->env_kind != KIND_CARTPOLE && c->env_kind != KIND_MOUNTAINCAR) return false;
     if (c->precision != GYMHIP_PRECISION_LOCKSTEP_F64 && c->precision != GYMHIP_PRECISION_F32) return false;
-    if (c->reset_mode != GYMHIP_RESET_TAPE && c->reset_mode != GYMHIP_RESET_COUNTER_RNG) return false;
+    if (c->reset_mode != GYMHIP_RESET_TAPE && c->reset_mode != GYMHIP_RESET_COUNTER_RNG && c->reset_mode != GYMHIP_RESET_MT19937) return false;
     if (c->n_envs <= 0 || c->env_offset < 0) return false;
     if ((c->wrappers & GYMHIP_WRAP_TIME_LIMIT) && c->max_episode_steps <= 0) return false;
     return true;
@@ -1110,6 +1261,9 @@ Layout make_layout(const gymhip_config& c) {
     L.ep_totals_global = take(4 * 8);
     L.error_flag = take(4);
     L.cursor_max = take(4);
+    L.reset_source = take(sizeof(ResetSource));
+    // MT19937: one std::mt19937 state array per env, 2,496 B each — 156 MiB at 65,536 envs, 39 GiB at 16.7 M (of 288 GB of HBM)
+    L.mt_state = (c.env_kind == KIND_CARTPOLE && c.reset_mode == GYMHIP_RESET_MT19937) ? take(n * (size_t)kMtWords * 4) : (size_t)-1;
     L.total = off;
     return L;
 }
@@ -1151,6 +1305,7 @@ struct gymhip_engine {
     bool stream_nt;          // step kernel streams with non-temporal accesses (footprint beyond the Infinity Cache)
     int keep_small;          // residency plan of an NT engine (plan_residency): the 4-B lanes that stay in the Infinity Cache, one of kPlans
     double* scratch_dev;     // this device's copy of the static `scratch` array (resolve_scratch)
+    bool mt;                 // CartPole with per-env std::mt19937 states on the device (GYMHIP_RESET_MT19937)
 
     template <typename T> T* at(size_t off) const { return off == (size_t)-1 ? nullptr : (T*)(ws + off); }
     float* stats_slot_ptr(int s) const { return at<float>(L.stats) + 16 * s; }
@@ -1171,7 +1326,7 @@ void plan_residency(gymhip_engine* h) {
         size_t budget = kMallBudget;
         if (const char* e = getenv("GYMHIP_MALL_MB")) budget = (size_t)std::max(0, atoi(e)) << 20;
         const bool returns = h->L.returns != (size_t)-1;
-        const bool tape = h->cfg.env_kind == KIND_CARTPOLE && h->cfg.reset_mode == GYMHIP_RESET_TAPE;
+        const bool tape = h->cfg.env_kind == KIND_CARTPOLE && (h->cfg.reset_mode == GYMHIP_RESET_TAPE || h->cfg.reset_mode == GYMHIP_RESET_MT19937);   // a per-reset gather either way
         for (int plan : kPlans) {
             if (tape && plan == kKeepAll) continue;   // measured: with the reset-tape gather in the mix the done lane is better streamed (0.707 vs 0.677 lockstep, 0.650 vs 0.635 float)
             int lanes = 0;
@@ -1189,14 +1344,13 @@ StepParams make_params(gymhip_engine* h) {
     StepParams p{};
     p.n = h->cfg.n_envs;
     p.env_offset = h->cfg.env_offset;
-    p.seed = h->cfg.seed;
+    p.src = h->at<ResetSource>(h->L.reset_source);
+    p.mt_state = h->at<uint32_t>(h->L.mt_state);
     p.wrappers = h->cfg.wrappers;
     p.max_episode_steps = h->cfg.max_episode_steps;
     p.reset_mode = h->cfg.reset_mode;
     p.gamma = h->cfg.gamma;
     p.lanes = h->lanes;
-    p.tape = h->tape;
-    p.tape_episodes = h->tape_episodes;
     p.error_flag = h->at<int32_t>(h->L.error_flag);
     p.partials = h->at<double>(h->L.partials);
     p.ep_partials = h->at<double>(h->L.ep_partials);
@@ -1226,6 +1380,25 @@ int check_handle(gymhip_engine* h) {
     return GYMHIP_OK;
 }
 
+// Publish the engine's reset source into its device block (ResetSource): kernels — also ones recorded into a HIP graph earlier —
+// read it from there.  Blocking; callers that replace a tape synchronise the device first.
+int push_reset_source(gymhip_engine* h) {
+    ResetSource rs{};
+    rs.tape = h->tape; rs.tape_episodes = h->tape_episodes; rs.seed = h->cfg.seed;
+    HIP_TRY(hipMemcpy(h->at<ResetSource>(h->L.reset_source), &rs, sizeof rs, hipMemcpyHostToDevice));
+    return GYMHIP_OK;
+}
+
+// (Re)seed every env's device-resident std::mt19937 (MT19937 engines): env i <- seed + env_offset + i, or the default-constructed
+// engine when `seeded` is false.  Enqueued on the null stream; the caller synchronises.
+int seed_generators(gymhip_engine* h, bool seeded, uint64_t seed) {
+    const int64_t n = h->cfg.n_envs;
+    const int g = (int)std::min<int64_t>(4096, (n + 255) / 256);
+    hipLaunchKernelGGL(mt_seed_kernel, dim3(g), dim3(256), 0, (hipStream_t) nullptr, h->at<uint32_t>(h->L.mt_state), n, seeded ? 1 : 0, seed, h->cfg.env_offset);
+    HIP_TRY(hipGetLastError());
+    return GYMHIP_OK;
+}
+
 // Device address of the static `scratch` array on `device` (which must be current).  Each GPU holds its own copy of the
 // array at its own address, so the lookup is done once per device and kept; the array's name itself is never passed to a
 // kernel or a copy.
@@ -1245,44 +1418,52 @@ int resolve_scratch(int device, double** out) {
     return GYMHIP_OK;
 }
 
-template <int KIND, bool LOCKSTEP, bool NORM, bool NT, int KEEP>
+template <int KIND, bool LOCKSTEP, bool NORM, bool NT, int KEEP, bool MT>
 void launch_step_act(gymhip_engine* h, const StepParams& p, int action_dtype, hipStream_t s) {
     switch (action_dtype) {
-        case GYMHIP_ACT_I32: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, int32_t, NORM, NT, KEEP>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
-        case GYMHIP_ACT_I64: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, int64_t, NORM, NT, KEEP>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
-        default: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, uint8_t, NORM, NT, KEEP>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
+        case GYMHIP_ACT_I32: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, int32_t, NORM, NT, KEEP, MT>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
+        case GYMHIP_ACT_I64: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, int64_t, NORM, NT, KEEP, MT>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
+        default: hipLaunchKernelGGL((step_kernel<KIND, LOCKSTEP, uint8_t, NORM, NT, KEEP, MT>), dim3(h->grid), dim3(kBlock), 0, s, p); break;
     }
 }
-template <int KIND, bool LOCKSTEP, bool NORM>
+template <int KIND, bool LOCKSTEP, bool NORM, bool MT>
 void launch_step_nt(gymhip_engine* h, const StepParams& p, int action_dtype, hipStream_t s) {
-    if (!h->stream_nt) { launch_step_act<KIND, LOCKSTEP, NORM, false, kKeepAll>(h, p, action_dtype, s); return; }
+    if (!h->stream_nt) { launch_step_act<KIND, LOCKSTEP, NORM, false, kKeepAll, MT>(h, p, action_dtype, s); return; }
     switch (h->keep_small) {   // one of kPlans (plan_residency)
-        case kKeepAll: launch_step_act<KIND, LOCKSTEP, NORM, true, kKeepAll>(h, p, action_dtype, s); break;
-        case kKeepNotDone: launch_step_act<KIND, LOCKSTEP, NORM, true, kKeepNotDone>(h, p, action_dtype, s); break;
-        case kKeepCounter: launch_step_act<KIND, LOCKSTEP, NORM, true, kKeepCounter>(h, p, action_dtype, s); break;
-        default: launch_step_act<KIND, LOCKSTEP, NORM, true, 0>(h, p, action_dtype, s); break;
+        case kKeepAll: launch_step_act<KIND, LOCKSTEP, NORM, true, kKeepAll, MT>(h, p, action_dtype, s); break;
+        case kKeepNotDone: launch_step_act<KIND, LOCKSTEP, NORM, true, kKeepNotDone, MT>(h, p, action_dtype, s); break;
+        case kKeepCounter: launch_step_act<KIND, LOCKSTEP, NORM, true, kKeepCounter, MT>(h, p, action_dtype, s); break;
+        default: launch_step_act<KIND, LOCKSTEP, NORM, true, 0, MT>(h, p, action_dtype, s); break;
     }
 }
-template <int KIND, bool LOCKSTEP>
+template <int KIND, bool LOCKSTEP, bool MT>
 void launch_step_norm(gymhip_engine* h, const StepParams& p, int action_dtype, hipStream_t s) {
-    if (h->norm) launch_step_nt<KIND, LOCKSTEP, true>(h, p, action_dtype, s);
-    else launch_step_nt<KIND, LOCKSTEP, false>(h, p, action_dtype, s);
+    if (h->norm) launch_step_nt<KIND, LOCKSTEP, true, MT>(h, p, action_dtype, s);
+    else launch_step_nt<KIND, LOCKSTEP, false, MT>(h, p, action_dtype, s);
 }
 template <int KIND>
 void launch_step_kind(gymhip_engine* h, const StepParams& p, int action_dtype, hipStream_t s) {
-    if (h->cfg.precision == GYMHIP_PRECISION_LOCKSTEP_F64) launch_step_norm<KIND, true>(h, p, action_dtype, s);
-    else launch_step_norm<KIND, false>(h, p, action_dtype, s);
+    const bool lock = h->cfg.precision == GYMHIP_PRECISION_LOCKSTEP_F64;
+    if constexpr (KIND == KIND_CARTPOLE) {
+        if (h->mt) { if (lock) launch_step_norm<KIND, true, true>(h, p, action_dtype, s); else launch_step_norm<KIND, false, true>(h, p, action_dtype, s); return; }
+    }
+    if (lock) launch_step_norm<KIND, true, false>(h, p, action_dtype, s);
+    else launch_step_norm<KIND, false, false>(h, p, action_dtype, s);
 }
 
-template <int KIND, bool LOCKSTEP>
+template <int KIND, bool LOCKSTEP, bool MT>
 void launch_reset_norm(gymhip_engine* h, const StepParams& p, hipStream_t s) {
-    if (h->norm) hipLaunchKernelGGL((reset_kernel<KIND, LOCKSTEP, true>), dim3(h->grid), dim3(kBlock), 0, s, p);
-    else hipLaunchKernelGGL((reset_kernel<KIND, LOCKSTEP, false>), dim3(h->grid), dim3(kBlock), 0, s, p);
+    if (h->norm) hipLaunchKernelGGL((reset_kernel<KIND, LOCKSTEP, true, MT>), dim3(h->grid), dim3(kBlock), 0, s, p);
+    else hipLaunchKernelGGL((reset_kernel<KIND, LOCKSTEP, false, MT>), dim3(h->grid), dim3(kBlock), 0, s, p);
 }
 template <int KIND>
 void launch_reset_kind(gymhip_engine* h, const StepParams& p, hipStream_t s) {
-    if (h->cfg.precision == GYMHIP_PRECISION_LOCKSTEP_F64) launch_reset_norm<KIND, true>(h, p, s);
-    else launch_reset_norm<KIND, false>(h, p, s);
+    const bool lock = h->cfg.precision == GYMHIP_PRECISION_LOCKSTEP_F64;
+    if constexpr (KIND == KIND_CARTPOLE) {
+        if (h->mt) { if (lock) launch_reset_norm<KIND, true, true>(h, p, s); else launch_reset_norm<KIND, false, true>(h, p, s); return; }
+    }
+    if (lock) launch_reset_norm<KIND, true, false>(h, p, s);
+    else launch_reset_norm<KIND, false, false>(h, p, s);
 }
 
 void launch_reduce_partials(gymhip_engine* h, hipStream_t s) {
@@ -1350,6 +1531,7 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
     h->norm = cfg->wrappers & (GYMHIP_WRAP_NORM_OBS | GYMHIP_WRAP_NORM_REWARD);
     h->tape = nullptr; h->tape_episodes = 0; h->tape_source = 0; h->tape_seeded = false; h->tape_seed = 0;
     h->did_reset = false; h->pending_finish = false; h->pending_is_reset = false;
+    h->mt = cfg->env_kind == KIND_CARTPOLE && cfg->reset_mode == GYMHIP_RESET_MT19937;
     // Plain (temporal) accesses win while everything a step touches stays in the 256 MiB Infinity Cache from one step to the next;
     // beyond that they thrash it and the engine streams non-temporally under a residency plan (plan_residency).  "Everything" is
     // the workspace plus the callers' action rows — the bench rotates four int32 rows, a trainer's policy has its own traffic — so
@@ -1357,8 +1539,9 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
     // 4.2 M (plain 0.79 | streaming 0.71) and 5.2 M envs (0.64 | 0.79); MountainCar lockstep between 5.8 M (0.79 | 0.75) and 6.3 M (0.67 | 0.74).
     size_t nt_footprint = kNtFootprint;
     if (const char* e = getenv("GYMHIP_NT_MB")) nt_footprint = (size_t)std::max(0, atoi(e)) << 20;   // sweeps only
-    h->stream_nt = kNtDefault && h->L.total + (size_t)cfg->n_envs * 16 > nt_footprint;
-    h->grid = grid_for(cfg->n_envs, h->norm, cfg->env_kind == KIND_CARTPOLE && cfg->precision == GYMHIP_PRECISION_LOCKSTEP_F64, h->stream_nt && cfg->reset_mode != GYMHIP_RESET_TAPE /* tape engines measure alike at 2048 and 16384 */, &h->lanes);
+    const size_t step_footprint = h->L.total - (h->mt ? (size_t)cfg->n_envs * kMtWords * 4 : 0);   // the generator states are touched by resets only
+    h->stream_nt = kNtDefault && step_footprint + (size_t)cfg->n_envs * 16 > nt_footprint;
+    h->grid = grid_for(cfg->n_envs, h->norm, cfg->env_kind == KIND_CARTPOLE && cfg->precision == GYMHIP_PRECISION_LOCKSTEP_F64, h->stream_nt && cfg->reset_mode == GYMHIP_RESET_COUNTER_RNG /* engines that gather a reset row (tape, per-env generators) are best at 2048: MT19937 0.2505 ms against 0.2626 at 16384 */, &h->lanes);
     plan_residency(h);
     if (int rc = resolve_scratch(device, &h->scratch_dev)) { delete h; return rc; }
     if (workspace) {
@@ -1380,6 +1563,10 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
         for (int s = 0; s < 3 && e == hipSuccess; s++) e = hipMemcpy(h->stats_slot_ptr(s), init, sizeof init, hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) { if (h->owns_ws) (void)hipFree(h->ws); delete h; return fail(GYMHIP_EHIP, "workspace init failed: %s", hipGetErrorString(e)); }
+    int rc = push_reset_source(h);
+    // MT19937: until VecEnv::seed is called every env holds a default-constructed std::mt19937 (env.h:83), as in the reference
+    if (rc == GYMHIP_OK && h->mt) { rc = seed_generators(h, false, 0); if (rc == GYMHIP_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(GYMHIP_EHIP, "seeding the per-env generators failed"); }
+    if (rc != GYMHIP_OK) { if (h->owns_ws) (void)hipFree(h->ws); delete h; return rc; }
     *out = h;
     return GYMHIP_OK;
 }
@@ -1409,13 +1596,21 @@ int gymhip_get_buffers(gymhip_engine* h, gymhip_buffers* out) {
     out->norm_stats = h->norm ? h->stats_slot_ptr(2) : nullptr;
     out->moments = h->at<double>(h->L.moments);
     out->episode_totals = h->at<double>(h->L.ep_totals);
+    out->mt_state = h->at<uint32_t>(h->L.mt_state);
     return GYMHIP_OK;
 }
 
+static int rewind_tape_cursors(gymhip_engine* h, hipStream_t s);
 int gymhip_seed(gymhip_engine* h, uint64_t seed) {
-    if (!h) return fail(GYMHIP_EINVAL, "null engine handle");
+    if (int rc = check_handle(h)) return rc;
     h->cfg.seed = seed;
-    return GYMHIP_OK;
+    HIP_TRY(hipDeviceSynchronize());                 // no stream argument: nothing of this engine may still be running on the old seed
+    if (h->mt) {                                     // Env::seed re-seeds the env's generator (env.h:60-63): every stream restarts
+        if (int rc = seed_generators(h, true, seed)) return rc;
+        if (int rc = rewind_tape_cursors(h, nullptr)) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    return push_reset_source(h);                     // COUNTER_RNG kernels (recorded ones too) read the seed from the device block
 }
 
 // every freshly loaded tape is read from row 0 again (see rewind_tape_cursor_kernel)
@@ -1425,15 +1620,21 @@ static int rewind_tape_cursors(gymhip_engine* h, hipStream_t s) {
     return GYMHIP_OK;
 }
 
+// A device tape of exactly `episodes` rows.  A tape of another size is replaced: the device is synchronised, the new rows are
+// allocated, the engine's device-side reset source is pointed at them, and only then is the old tape freed — so a step recorded into
+// a HIP graph before the change gathers from the NEW tape when it is replayed (it reads pointer and row count from the device block).
 static int ensure_tape(gymhip_engine* h, int64_t episodes) {
     if (h->cfg.env_kind != KIND_CARTPOLE) return fail(GYMHIP_EINVAL, "only CartPole draws its reset state (MountainCar resets are constant)");
+    if (h->mt) return fail(GYMHIP_EINVAL, "an MT19937 engine draws its reset states from per-env generators on the device: seed it with gymhip_seed");
     if (episodes <= 0) return fail(GYMHIP_EINVAL, "episodes must be positive");
-    if (h->tape && h->tape_episodes != episodes) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(h->tape)); h->tape = nullptr; h->tape_episodes = 0; }
-    if (!h->tape) {
-        void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, (size_t)episodes * h->cfg.n_envs * 16));
-        h->tape = (float*)p; h->tape_episodes = episodes;
-    }
+    if (h->tape && h->tape_episodes == episodes) return GYMHIP_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, (size_t)episodes * h->cfg.n_envs * 16));
+    float* old = h->tape;
+    h->tape = (float*)p; h->tape_episodes = episodes;
+    if (int rc = push_reset_source(h)) return rc;
+    if (old) HIP_TRY(hipFree(old));
     return GYMHIP_OK;
 }
 
@@ -1491,6 +1692,7 @@ static int draw_reset_tape(gymhip_engine* h, bool seeded, uint64_t seed, int64_t
     if (seeded) h->cfg.seed = seed;
     h->tape_source = 1; h->tape_seeded = seeded; h->tape_seed = seed;
     HIP_TRY(hipDeviceSynchronize());
+    if (int rc = push_reset_source(h)) return rc;
     HIP_TRY(hipMemcpy(h->tape, tape.data(), tape.size() * sizeof(float), hipMemcpyHostToDevice));
     if (rewind) { if (int rc = rewind_tape_cursors(h, nullptr)) return rc; }
     HIP_TRY(hipDeviceSynchronize());
@@ -1503,7 +1705,7 @@ int gymhip_tape_cursor_max(gymhip_engine* h, int32_t* host_out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int32_t* slot = h->at<int32_t>(h->L.cursor_max);
     HIP_TRY(hipMemsetAsync(slot, 0, 4, s));
-    if (h->cfg.env_kind == KIND_CARTPOLE && h->cfg.reset_mode == GYMHIP_RESET_TAPE)
+    if (h->cfg.env_kind == KIND_CARTPOLE && (h->cfg.reset_mode == GYMHIP_RESET_TAPE || h->mt))
         hipLaunchKernelGGL(tape_cursor_max_kernel, dim3(h->grid), dim3(kBlock), 0, s, h->at<uint32_t>(h->L.counter), h->cfg.n_envs, slot);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_out, slot, 4, hipMemcpyDeviceToHost, s));
@@ -1598,7 +1800,10 @@ int gymhip_rollout(gymhip_engine* h, const uint8_t* action_tape, int64_t k_steps
     StepParams p = make_params(h);
     const bool lock = h->cfg.precision == GYMHIP_PRECISION_LOCKSTEP_F64;
     dim3 g(h->grid), bdim(kBlock);
-    if (h->cfg.env_kind == KIND_CARTPOLE) {
+    if (h->mt) {
+        if (lock) hipLaunchKernelGGL((rollout_kernel<KIND_CARTPOLE, true, true>), g, bdim, 0, s, p, action_tape, k_steps, rec_done, rec_reward, rec_truncated, rec_obs);
+        else hipLaunchKernelGGL((rollout_kernel<KIND_CARTPOLE, false, true>), g, bdim, 0, s, p, action_tape, k_steps, rec_done, rec_reward, rec_truncated, rec_obs);
+    } else if (h->cfg.env_kind == KIND_CARTPOLE) {
         if (lock) hipLaunchKernelGGL((rollout_kernel<KIND_CARTPOLE, true>), g, bdim, 0, s, p, action_tape, k_steps, rec_done, rec_reward, rec_truncated, rec_obs);
         else hipLaunchKernelGGL((rollout_kernel<KIND_CARTPOLE, false>), g, bdim, 0, s, p, action_tape, k_steps, rec_done, rec_reward, rec_truncated, rec_obs);
     } else {
@@ -1675,7 +1880,10 @@ int gymhip_reset_index(gymhip_engine* h, int64_t index, void* stream) {
     float* on = (h->cfg.wrappers & GYMHIP_WRAP_NORM_OBS) ? h->at<float>(h->L.obs_norm) : nullptr;
     const bool lock = h->cfg.precision == GYMHIP_PRECISION_LOCKSTEP_F64;
     hipStream_t s = (hipStream_t)stream;
-    if (h->cfg.env_kind == KIND_CARTPOLE) {
+    if (h->mt) {
+        if (lock) hipLaunchKernelGGL((reset_index_kernel<KIND_CARTPOLE, true, true>), dim3(1), dim3(64), 0, s, p, index, on, h->cfg.clip_obs, h->cfg.epsilon);
+        else hipLaunchKernelGGL((reset_index_kernel<KIND_CARTPOLE, false, true>), dim3(1), dim3(64), 0, s, p, index, on, h->cfg.clip_obs, h->cfg.epsilon);
+    } else if (h->cfg.env_kind == KIND_CARTPOLE) {
         if (lock) hipLaunchKernelGGL((reset_index_kernel<KIND_CARTPOLE, true>), dim3(1), dim3(64), 0, s, p, index, on, h->cfg.clip_obs, h->cfg.epsilon);
         else hipLaunchKernelGGL((reset_index_kernel<KIND_CARTPOLE, false>), dim3(1), dim3(64), 0, s, p, index, on, h->cfg.clip_obs, h->cfg.epsilon);
     } else {

@@ -18,13 +18,20 @@ struct StepBuffers {
     float* returns;          // f32 [N] or null
 };
 
+// Where reset states come from, as DEVICE state (one block per engine, in its workspace): kernels read it through a pointer, so a
+// step recorded into a HIP graph keeps following the engine when the host re-seeds it or replaces / extends its reset tape.
+struct ResetSource {
+    const float* tape;       // TAPE: f32 [tape_episodes][N][4], host-drawn or device-generated; else null
+    int64_t tape_episodes;
+    uint64_t seed;           // COUNTER_RNG: keys the stateless draw together with the global env index and the env's episode index
+};
+
 struct StepParams {
     int64_t n;
     int64_t env_offset;
-    uint64_t seed;
     const void* actions;
-    const float* tape;       // f32 [tape_episodes][N][4]
-    int64_t tape_episodes;
+    const ResetSource* src;  // device
+    uint32_t* mt_state;      // MT19937: u32 [N][624], env i's std::mt19937 state array (libstdc++ _M_x), twisted in place; else null
     const float* stats;      // running statistics, two ping-pong slots of 16 floats (+ the public copy), or null; the current slot is *tick_w & 1
     const int32_t* tick_w;   // device-side slot hand-off (see normalize_kernel): kernels that only READ the statistics take the slot from
     int32_t* tick_r;         // tick_w and copy it into tick_r; the kernel that PUBLISHES new statistics reads tick_r and bumps tick_w

@@ -77,6 +77,8 @@ class Engine:
         self.norm_stats = self._view(b.norm_stats, torch.float32, (2 * F + 4,))
         self.moments = self._view(b.moments, torch.float64, (self.moments_len,))
         self.episode_totals = self._view(b.episode_totals, torch.float64, (3,))
+        # MT19937 engines: env i's std::mt19937 state array (u32 [N][624], untempered words; int32 view of the same bits)
+        self.mt_state = self._view(b.mt_state, torch.int32, (n, 624))
         # LOCKSTEP: int32 residual rows of the split-double state (gymhip.h); state_f64() joins them with obs
         self.state_residual = self._view(b.state, torch.int32, (n, F)) if cfg.precision == L.PRECISION_LOCKSTEP_F64 else None
 
@@ -144,6 +146,8 @@ class Engine:
         return out
 
     def seed(self, seed: int):
+        """VecEnv::seed: MT19937 engines re-seed every env's device-resident std::mt19937 (seed + env_offset + i); COUNTER_RNG
+        engines re-key their draw.  Synchronises the device."""
         L.check(self.lib.gymhip_seed(self.h, seed), "gymhip_seed")
 
     # ---- stepping -------------------------------------------------------------------------------------

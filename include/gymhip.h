@@ -29,9 +29,20 @@ enum { GYMHIP_ENV_CARTPOLE = 0, GYMHIP_ENV_MOUNTAINCAR = 1 };
 /* LOCKSTEP_F64: the reference's exact op sequence and precisions (double state, float where it narrows) — bit-exact
  * streams.  F32: float state == the observation buffer, one 16-B read-modify-write per env (throughput mode). */
 enum { GYMHIP_PRECISION_LOCKSTEP_F64 = 0, GYMHIP_PRECISION_F32 = 1 };
-/* TAPE: k-th reset of env i reads tape[k][i][0..3] (host-drawn std::mt19937, cartpole.cpp:19-31).
- * COUNTER_RNG: stateless hash(seed, global env, episode) with the same float distribution arithmetic. */
-enum { GYMHIP_RESET_TAPE = 0, GYMHIP_RESET_COUNTER_RNG = 1 };
+/* Where CartPole's reset states come from (cartpole.cpp:19-31; MountainCar's reset is constant, mountain_car.cpp:38-42).
+ * TAPE: the k-th reset of env i reads tape[k][i][0..3], rows drawn on the HOST with std::mt19937 and uploaded (or any rows the
+ *   caller supplies).  Finite; what the lockstep parity tests pin everything else against.
+ * MT19937: every env owns the state array of a std::mt19937 ON THE DEVICE (2,496 B per env, part of the workspace) and the step
+ *   kernel draws from it as the reference's CartPoleEnv::reset does from m_Device (env.h:83): libstdc++'s seeding, twist,
+ *   tempering and uniform_real_distribution<float>(-0.05f, 0.05f) arithmetic in integer / float32 on the GPU, bit-identical to the
+ *   host-drawn tape for any number of episodes — no refill, no host work, no PCIe traffic.  Until gymhip_seed() is called the
+ *   generators are default-constructed (all envs draw the same stream), exactly as the reference's envs are before VecEnv::seed.
+ *   Why not draw on the host at scale: 16.7 M envs finish ~7.5e5 episodes per 0.25-ms step — 4 x 10^9 draws/s more than 16 host
+ *   cores produce, and 48 GB/s of rows over PCIe.
+ * COUNTER_RNG: stateless hash(seed, global env index, the env's episode index) with the same float distribution arithmetic — same
+ *   distribution, NOT the reference's stream.  The episode index is a 20-bit field of the env's counter word: after 2^20 episodes
+ *   of one env (>= 8.4e6 steps) its reset states repeat with that period; the first wrap sets bit 4 of the error word. */
+enum { GYMHIP_RESET_TAPE = 0, GYMHIP_RESET_COUNTER_RNG = 1, GYMHIP_RESET_MT19937 = 2 };
 /* wrappers/time_limit.h, wrappers/clip_reward.h, wrappers/monitor.h, wrappers/vec_env/vec_normalize.h */
 enum {
     GYMHIP_WRAP_TIME_LIMIT = 1u,
@@ -82,7 +93,8 @@ typedef struct gymhip_buffers {
                                        records and the tape cursor cost no HBM traffic of their own):
                                          bit 31      the LAST step finished an episode and auto-reset the env
                                          bit 30      that episode's info["TimeLimit.truncated"] (time_limit.h:32)
-                                         bits S..29  reset-tape rows consumed so far (TAPE mode), else 0
+                                         bits S..29  CartPole: reset rows the env has consumed (TAPE: tape rows; MT19937: generator
+                                                     rows mod 1,048,320; COUNTER_RNG: episode index mod 2^20), else 0
                                          bits 0..S-1 bit 31 set: the finished episode's length (info["episode"].l,
                                                      monitor.h:86); clear: steps since the last reset
                                                      (TimeLimit::elapsedSteps == Monitor::_steps == CartPole timeStep)
@@ -91,6 +103,9 @@ typedef struct gymhip_buffers {
     float* norm_stats;              /* f32 [2F+4]: obs mean[F], obs var[F], obs count, ret mean, ret var, ret count */
     double* moments;                /* f64 [moments_len] all-reduce payload of the step in flight */
     double* episode_totals;         /* f64 [3] cumulative episodes, sum of returns, sum of lengths (after gymhip_episode_stats) */
+    uint32_t* mt_state;             /* MT19937 engines: u32 [N][624], env i's std::mt19937 state array (libstdc++'s _M_x, untempered);
+                                       its read position is (cursor % 156) * 4 words, a block being regenerated when a reset finds
+                                       cursor % 156 == 0.  Together with `counter` this is the generator: copy both to checkpoint it */
 } gymhip_buffers;
 
 const char* gymhip_last_error(void);
@@ -106,8 +121,11 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
 int gymhip_destroy(gymhip_engine* h);
 int gymhip_get_buffers(gymhip_engine* h, gymhip_buffers* out);
 
-/* VecEnv::seed (base.h:74, sync_env.h:74-83): env i <- seed + env_offset + i.  Affects COUNTER_RNG resets; in TAPE
- * mode the tape itself carries the seed (draw it with the same rule). */
+/* VecEnv::seed (base.h:74, sync_env.h:74-83): env i <- seed + env_offset + i.  MT19937: re-seeds every env's device-resident
+ * std::mt19937 (libstdc++'s seed(value): x[0] = value mod 2^32, ...) and restarts its stream, as Env::seed does (env.h:60-63).
+ * COUNTER_RNG: re-keys the stateless draw.  TAPE: the tape itself carries the seed (gymhip_seed_reset_tape).
+ * Synchronises the device.  The seed is device state (kernels read it through the engine's reset-source block), so a step recorded
+ * into a HIP graph before the call draws with the NEW seed when replayed. */
 int gymhip_seed(gymhip_engine* h, uint64_t seed);
 
 /* Host-drawn reset tape f32 [episodes][n_envs][4] (CartPole; cartpole.cpp:19-31 + env.h:60-68 semantics), copied to the
@@ -142,9 +160,12 @@ int gymhip_reset(gymhip_engine* h, void* stream);
 /* VecEnv::step(actions) = stepAsync + stepWait (base.h:56-63; sync_env.h:85-123; vec_normalize.h:159-177).
  * `actions` is a device array of n_envs elements of `action_dtype` (the reference narrows any tensor to int32,
  * tensor_adapter.cpp:22-23).  gymhip_step == gymhip_step_begin + gymhip_step_finish.
- * Stream capture: a step neither allocates nor synchronises, and all per-step state (tape cursor / counter-RNG episode index per
- * env, the normaliser's current statistics slot) lives on the device: gymhip_step / gymhip_reset may be recorded into a HIP graph
- * and replayed; the caller rewrites its static action buffer between replays. */
+ * Stream capture: a step neither allocates nor synchronises, and all per-step state (tape cursor / generator row / counter-RNG
+ * episode index per env, the normaliser's current statistics slot) AND the reset source itself (tape pointer, tape rows, seed: a
+ * device-side block the kernels read through a pointer) live on the device: gymhip_step / gymhip_reset may be recorded into a HIP
+ * graph and replayed; the caller rewrites its static action buffer between replays.  A recorded step stays valid across
+ * gymhip_seed, gymhip_seed_reset_tape / _extend_reset_tape / _upload_reset_tape / _generate_reset_tape (a replaced tape is freed
+ * only after the block points at the new one; tests/test_gpu_graph_capture.py). */
 int gymhip_step(gymhip_engine* h, const void* actions, int action_dtype, void* stream);
 /* Split form for sharded runs with the normaliser on: after _begin the `moments` buffer holds this rank's batch
  * moments + episode statistics; the caller all-reduces (sum) it over ranks (RCCL) on `stream`, then calls _finish,
@@ -178,7 +199,8 @@ int gymhip_episode_stats(gymhip_engine* h, double* host_out, void* stream);
 /* Sticky device error word: bit0 = reset tape exhausted (an env needed more episodes than were uploaded; rows wrap),
  * bit1 = an env's tape-cursor field overflowed (2^20 episodes), bit2 = a LOCKSTEP state value left the split-double
  * range (non-finite, or nonzero below 2^-126 — the dynamics never produce either), bit3 = with GYMHIP_WRAP_NO_AUTO_RESET a
- * finished env was stepped again before its gymhip_reset_index(). */
+ * finished env was stepped again before its gymhip_reset_index().  bit4 is information, not an error: a COUNTER_RNG env's
+ * 20-bit episode index wrapped (its reset states repeat from here on with period 2^20; use MT19937 for a stream that never does). */
 int gymhip_poll_error(gymhip_engine* h, int32_t* host_out, void* stream);
 /* Diagnostics, no counterpart in the reference: the launch shape and cache policy gymhip_create chose for this engine
  *  — out[0] = workgroups of the step / reset kernels, out[1] = threads per workgroup that own envs,

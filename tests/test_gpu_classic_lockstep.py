@@ -308,3 +308,27 @@ def test_rollout_of_k_steps_equals_k_step_calls(kind, precision, reset_mode):
         assert torch.equal(a.done, b.done) and torch.equal(a.reward, b.reward)
     assert np.array_equal(a.episode_stats(), b.episode_stats()) and a.episode_stats()[0] > n
     assert a.poll_error() == 0 and b.poll_error() == 0
+
+
+def test_counter_rng_episode_index_wraps_after_2_pow_20_episodes_and_says_so():
+    """COUNTER_RNG keys an env's reset draw by a 20-bit episode index kept in its counter word (gymhip.h): after 2^20 episodes of one
+    env the reset states repeat with that period.  Documented, and reported: the wrap sets bit 4 of the error word (information; no
+    other bit).  TimeLimit(1) makes every step an episode; the rollout kernel takes the 2^20 steps in 16 launches."""
+    from gym_amd import _lib as L
+    n, K = 64, 1 << 16
+    eng = make_engine(L.ENV_CARTPOLE, n, L.PRECISION_LOCKSTEP_F64, L.WRAP_TIME_LIMIT | L.WRAP_MONITOR, 1, reset_mode=L.RESET_COUNTER_RNG, seed=3)
+    eng.reset()
+    head = torch.zeros((8, n), dtype=torch.uint8, device="cuda")
+    rec_a = torch.empty((8, n, 4), dtype=torch.float32, device="cuda")
+    eng.rollout(head, rec_obs=rec_a)                          # episode indices 1..8: with TimeLimit(1) every observation is a reset state
+    assert eng.poll_error() == 0
+    tape = torch.zeros((K, n), dtype=torch.uint8, device="cuda")
+    for _ in range((1 << 20) // K - 1):
+        eng.rollout(tape)
+    eng.rollout(tape[:K - 8])
+    assert eng.poll_error() == 16                             # the index wrapped to 0 on the way
+    assert int(eng.counters()["cursor"].min()) == int(eng.counters()["cursor"].max()) == 1
+    rec_b = torch.empty_like(rec_a)
+    eng.rollout(head, rec_obs=rec_b)
+    assert torch.equal(rec_a, rec_b)                          # the same reset states again: period 2^20 episodes per env
+    assert eng.episode_stats()[0] == n * ((1 << 20) + 8)

@@ -139,3 +139,47 @@ def test_counter_rng_resets_equal_a_tape_filled_by_the_same_generator():
             assert torch.equal(rng.obs, tape.obs) and torch.equal(rng.counter, tape.counter)
     assert torch.equal(rng.state_f64(), tape.state_f64())
     assert rng.poll_error() == 0 and tape.poll_error() == 0 and rng.episode_stats()[0] == tape.episode_stats()[0] > 5 * n
+
+
+def test_recorded_step_follows_a_replaced_reset_tape_and_a_new_seed(oracle):
+    """The reset source is device state (a block the kernels read through a pointer), not launch arguments: a step recorded BEFORE
+    gymhip_extend_reset_tape — which allocates a larger tape and frees the old one — gathers from the new tape when replayed (it used
+    to read freed memory with the old row count), and a recorded COUNTER_RNG step draws with the seed gymhip_seed() set afterwards."""
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+    n, T, seed, tl = 2000, 160, 8, 6
+    mk = lambda mode: Engine(EngineConfig(env_kind=L.ENV_CARTPOLE, n_envs=n, precision=L.PRECISION_LOCKSTEP_F64, reset_mode=mode,
+                                          wrappers=L.WRAP_TIME_LIMIT | L.WRAP_MONITOR, max_episode_steps=tl, seed=seed), 0)
+    for mode in (L.RESET_TAPE, L.RESET_COUNTER_RNG):
+        graphed, eager = mk(mode), mk(mode)
+        if mode == L.RESET_TAPE:
+            graphed.seed_reset_tape(seed, 12)          # 12 rows: exhausted after ~70 steps of TimeLimit(6)
+            eager.seed_reset_tape(seed, T)             # the eager twin has the whole tape from the start
+        graphed.reset(); eager.reset()
+        g_ = torch.Generator(device="cuda").manual_seed(4)
+        acts = torch.randint(0, 2, (T, n), dtype=torch.int32, device="cuda", generator=g_)
+        static_actions = acts[0].clone()
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            graphed.step(static_actions)
+        side.synchronize()
+        eager.step(acts[0])
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            graphed.step(static_actions)
+        for t in range(1, T):
+            if t == 40:
+                torch.cuda.synchronize()
+                if mode == L.RESET_TAPE:
+                    graphed.extend_reset_tape(T)       # new allocation, old tape freed; the graph is NOT re-recorded
+                else:
+                    graphed.seed(seed + 5); eager.seed(seed + 5)
+            static_actions.copy_(acts[t])
+            g.replay()
+            eager.step(acts[t])
+            torch.cuda.synchronize()
+            for name in ("obs", "reward", "done", "counter"):
+                assert torch.equal(getattr(graphed, name), getattr(eager, name)), (mode, t, name)
+        assert graphed.poll_error() == 0 and eager.poll_error() == 0
+        assert graphed.episode_stats()[0] > n * (T // tl - 1)
