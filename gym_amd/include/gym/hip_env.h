@@ -58,17 +58,13 @@ public:
         Env<std::vector<double>, int>::seed(_seed);   // keeps m_Device in step with the reference's member (env.h:60-68)
         if (!_seed) { std::fprintf(stderr, "HipClassicEnv::seed(nullopt): the engine needs a reproducible seed; keeping the current stream\n"); return; }
         seeded = true; seed_value = *_seed;
-        if (h && KIND == GYMHIP_ENV_CARTPOLE) { if (ok(gymhip_seed_reset_tape(h, seed_value, tape_rows), "gymhip_seed_reset_tape")) resets = 0; }
+        if (h && KIND == GYMHIP_ENV_CARTPOLE) ok(gymhip_seed(h, seed_value), "gymhip_seed");   // re-seeds the env's device-resident std::mt19937 (env.h:60-63)
     }
 
     std::vector<double> reset() noexcept override {
         if (!ensure()) return {};
-        if (KIND == GYMHIP_ENV_CARTPOLE && resets + 1 >= tape_rows) {   // one tape row per reset: extend the same stream before it runs out
-            if (!ok(gymhip_extend_reset_tape(h, tape_rows * 2), "gymhip_extend_reset_tape")) return {};
-            tape_rows *= 2;
-        }
         if (!ok(did_reset ? gymhip_reset_index(h, 0, nullptr) : gymhip_reset(h, nullptr), "gymhip_reset")) return {};
-        did_reset = true; resets++; finished = false;
+        did_reset = true; finished = false;
         return state();
     }
 
@@ -104,7 +100,7 @@ private:
         if (hipSetDevice(device) != hipSuccess) return false;
         gymhip_config c{};
         c.struct_size = sizeof c; c.env_kind = KIND; c.precision = GYMHIP_PRECISION_LOCKSTEP_F64;
-        c.reset_mode = KIND == GYMHIP_ENV_CARTPOLE ? GYMHIP_RESET_TAPE : GYMHIP_RESET_COUNTER_RNG;
+        c.reset_mode = KIND == GYMHIP_ENV_CARTPOLE ? GYMHIP_RESET_MT19937 : GYMHIP_RESET_COUNTER_RNG;   // the env's own std::mt19937 (env.h:83), on the device
         c.wrappers = GYMHIP_WRAP_NO_AUTO_RESET;   // the bare env: no TimeLimit / Monitor / auto-reset
         c.n_envs = 1; c.seed = seeded ? seed_value : 0;
         c.clip_obs = 10.f; c.clip_reward = 10.f; c.gamma = 0.99f; c.epsilon = 1e-8f;
@@ -115,7 +111,7 @@ private:
             if (dev_state) { (void)hipFree(dev_state); dev_state = nullptr; }
             return false;
         };
-        if (KIND == GYMHIP_ENV_CARTPOLE && !ok(seeded ? gymhip_seed_reset_tape(h, seed_value, tape_rows) : gymhip_unseeded_reset_tape(h, tape_rows), "reset tape")) return giveUp();
+        if (KIND == GYMHIP_ENV_CARTPOLE && seeded && !ok(gymhip_seed(h, seed_value), "gymhip_seed")) return giveUp();   // never seeded = default-constructed generator
         if (!ok(gymhip_get_buffers(h, &buf), "gymhip_get_buffers")) return giveUp();
         if (hipMalloc((void**)&dev_action, 4) != hipSuccess || hipMalloc((void**)&dev_state, F * sizeof(double)) != hipSuccess) return giveUp();
         return true;
@@ -128,7 +124,6 @@ private:
     double* dev_state = nullptr;
     bool seeded = false, did_reset = false, finished = false;
     uint64_t seed_value = 0;
-    int64_t tape_rows = 64, resets = 0;
 };
 
 using HipCartPoleEnv = HipClassicEnv<GYMHIP_ENV_CARTPOLE>;

@@ -47,9 +47,11 @@ struct HipVecEnvOptions {
     bool auto_reset = true;                   // SyncVecEnv(envs, auto_reset) (sync_env.h:28,44,92): false = a finished env keeps its terminal
                                               // observation and waits for reset(index)
     bool lockstep = true;                     // reference-exact arithmetic (double state); false = float-state throughput mode
-    bool host_drawn_resets = true;            // std::mt19937 reset tape (reference-exact); false = stateless counter RNG
-    int64_t tape_episodes = 0;                // reset-tape rows per env to start with; 0 = at most 256 MiB of rows, 8..2048 per env.
-                                              // The tape is extended (same std::mt19937 streams, twice the rows) before any env runs out.
+    bool reference_resets = true;             // CartPole reset states from the reference's own per-env std::mt19937 streams (env.h:83,
+                                              // cartpole.cpp:19-31); false = stateless counter RNG (same distribution, other stream)
+    int64_t tape_episodes = 0;                // 0: the generators live ON THE DEVICE (GYMHIP_RESET_MT19937: no refill, no host work).
+                                              // > 0: the streams are drawn on the HOST into a reset tape of this many rows per env to start
+                                              // with (GYMHIP_RESET_TAPE), extended — same streams, twice the rows — before any env runs out
     bool norm_obs = false, norm_reward = false, training = true;   // VecNormalize<false, training, normReward, normObs>
     float clip_obs = 10.f, clip_rew = 10.f, gamma = 0.99f, epsilon = 1e-8f;   // vec_normalize.h:24-27
     int device = 0;
@@ -74,7 +76,7 @@ public:
         seeded = true; seed_value = _seed;
         if (h) {   // mid-run re-seed: every env's generator restarts, exactly as Env::seed does (env.h:60-63)
             if (usesTape()) { if (ok(gymhip_seed_reset_tape(h, _seed, tape_rows), "gymhip_seed_reset_tape")) tape_budget = tapeStepsFor(tape_rows); }
-            else ok(gymhip_seed(h, _seed), "gymhip_seed");
+            else ok(gymhip_seed(h, _seed), "gymhip_seed");   // device generators re-seeded / counter RNG re-keyed
         }
         std::vector<size_t> s(numEnvs);
         for (int i = 0; i < numEnvs; i++) s[i] = _seed + (size_t)opt.env_offset + (size_t)i;
@@ -261,7 +263,7 @@ private:
         c.env_kind = opt.env_kind;
         c.precision = opt.lockstep ? GYMHIP_PRECISION_LOCKSTEP_F64 : GYMHIP_PRECISION_F32;
         const bool tape = usesTape();
-        c.reset_mode = tape ? GYMHIP_RESET_TAPE : GYMHIP_RESET_COUNTER_RNG;
+        c.reset_mode = tape ? GYMHIP_RESET_TAPE : (opt.reference_resets ? GYMHIP_RESET_MT19937 : GYMHIP_RESET_COUNTER_RNG);
         auto flag = [](bool on, uint32_t bit) { return on ? bit : 0u; };
         c.wrappers = flag(opt.max_episode_steps > 0, GYMHIP_WRAP_TIME_LIMIT) | flag(opt.clip_reward, GYMHIP_WRAP_CLIP_REWARD) |
                      flag(opt.monitor, GYMHIP_WRAP_MONITOR) | flag(opt.norm_obs, GYMHIP_WRAP_NORM_OBS) |
@@ -274,9 +276,11 @@ private:
         // any failure after create leaves NO half-built engine behind: the handle is destroyed and the next call starts over
         auto giveUp = [this]() { gymhip_destroy(h); h = nullptr; return false; };
         if (tape) {
-            if (tape_rows <= 0) tape_rows = opt.tape_episodes > 0 ? opt.tape_episodes : std::min<int64_t>(2048, std::max<int64_t>(8, ((int64_t)256 << 20) / (16 * std::max<int64_t>(1, opt.n_envs))));
+            if (tape_rows <= 0) tape_rows = opt.tape_episodes;
             if (!ok(seeded ? gymhip_seed_reset_tape(h, seed_value, tape_rows) : gymhip_unseeded_reset_tape(h, tape_rows), "reset tape")) return giveUp();
             tape_budget = tapeStepsFor(tape_rows);
+        } else if (c.reset_mode == GYMHIP_RESET_MT19937 && seeded) {
+            if (!ok(gymhip_seed(h, seed_value), "gymhip_seed")) return giveUp();   // never seeded = default-constructed generators, as in the reference
         }
         if (!ok(gymhip_get_buffers(h, &buf), "gymhip_get_buffers")) return giveUp();
         const int64_t n = opt.n_envs, F = buf.obs_dim;
@@ -294,7 +298,7 @@ private:
     // min(8, TimeLimit) steps (cartpole.cpp:19-68, enumerated), so with r rows left for the env that consumed most, 8 (r - 1)
     // further steps cannot exhaust the tape.  When that budget is spent: one 4-byte read-back of the largest cursor, and with
     // under a quarter of the rows left the tape is redrawn from the same std::mt19937 streams with twice the rows.
-    bool usesTape() const { return opt.host_drawn_resets && opt.env_kind == GYMHIP_ENV_CARTPOLE; }
+    bool usesTape() const { return opt.reference_resets && opt.tape_episodes > 0 && opt.env_kind == GYMHIP_ENV_CARTPOLE; }
     int64_t minEpisodeSteps() const { return opt.max_episode_steps > 0 ? std::max<int64_t>(1, std::min<int64_t>(8, opt.max_episode_steps)) : 8; }
     int64_t tapeStepsFor(int64_t rows_left) const { return std::max<int64_t>(0, minEpisodeSteps() * (rows_left - 1)); }
     bool tapeSpend(int64_t steps) noexcept {

@@ -157,7 +157,7 @@ class HipVecEnv(VecEnv):
     """
 
     def __init__(self, env_id: str, n_envs: int, max_episode_steps: int | None = None, clip_reward: bool = False, monitor: bool = True,
-                 lockstep: bool = True, reset_mode: str = "tape", tape_episodes: int | None = None, device: int | None = None,
+                 lockstep: bool = True, reset_mode: str | None = None, tape_episodes: int | None = None, device: int | None = None,
                  rank: int | None = None, world: int | None = None, process_group=None, auto_reset: bool = True):
         if env_id not in _ENV_IDS:
             raise ValueError(f"unknown env id {env_id!r}; the engine implements {sorted(_ENV_IDS)}")
@@ -175,7 +175,14 @@ class HipVecEnv(VecEnv):
                           (0 if auto_reset else L.WRAP_NO_AUTO_RESET))
         self._max_steps = int(max_episode_steps or 0)
         self._lockstep = lockstep
-        self._reset_mode = L.RESET_TAPE if (reset_mode == "tape" and self.kind == L.ENV_CARTPOLE) else L.RESET_COUNTER_RNG
+        # CartPole's reset source: "mt19937" (default) = every env's std::mt19937 on the device — the reference's own streams, for ever,
+        # no host work; "tape" (or a given tape_episodes) = the same streams drawn on the host into a finite tape that is extended on
+        # demand; "rng" = stateless counter RNG (same distribution, not the reference's stream)
+        if reset_mode is None:
+            reset_mode = "tape" if tape_episodes is not None else "mt19937"
+        if reset_mode not in ("mt19937", "tape", "rng"):
+            raise ValueError(f"reset_mode {reset_mode!r}: expected 'mt19937', 'tape' or 'rng'")
+        self._reset_mode = L.RESET_COUNTER_RNG if (reset_mode == "rng" or self.kind != L.ENV_CARTPOLE) else (L.RESET_TAPE if reset_mode == "tape" else L.RESET_MT19937)
         # Host-drawn reset tape: start with at most 256 MiB of rows (16 B each), at least 8 and at most 2048 per env; the tape
         # guard below extends it (same streams, twice the rows) before any env can run out.
         if tape_episodes is None:
@@ -215,6 +222,8 @@ class HipVecEnv(VecEnv):
             else:
                 self.engine.seed_reset_tape(self._seed, self._tape_episodes)
             self._tape_budget = self._tape_steps_for(self._tape_episodes)
+        elif self._reset_mode == L.RESET_MT19937 and self._seed is not None:
+            self.engine.seed(self._seed)   # never seeded = default-constructed generators, as in the reference
 
     # -- reset-tape guard ------------------------------------------------------------------------------------------
     # An env consumes one tape row per finished episode (and per reset).  No CartPole episode is shorter than 8 steps

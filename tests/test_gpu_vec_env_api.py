@@ -376,3 +376,30 @@ def test_the_references_own_smoke_scenarios_at_their_sizes(oracle):
         r = ov.step(acts[t])
         assert np.array_equal(s.observation.cpu().numpy(), r["obs"]) and np.array_equal(s.done.cpu().numpy()[:, 0], r["done"]), t
     assert env.engine.poll_error() == 0
+
+
+@pytest.mark.parametrize("seed", [None, 17])
+def test_default_reset_source_is_the_device_resident_mt19937_and_matches_the_oracle(oracle, seed):
+    """HipVecEnv without a reset_mode / tape_episodes: every env's std::mt19937 lives on the device (GYMHIP_RESET_MT19937) — no tape,
+    no tape guard — and the streams are the reference's: seeded `seed + i` (sync_env.h:74-83) or never seeded (env.h:83), a mid-run
+    re-seed included, against the oracle's per-env generators over ~3 regenerations of every generator block."""
+    from gym_amd import _lib as L
+    from gym_amd.vec_env import HipVecEnv
+    n, T = 700, 1500
+    env = HipVecEnv("CartPole-v1", n, max_episode_steps=3)
+    ov = oracle.vec(CARTPOLE, n, F_TIME_LIMIT | F_MONITOR, 3)
+    if seed is not None:
+        assert list(env.seed(seed)) == [seed + i for i in range(n)]
+        ov.seed(seed)
+    assert env._reset_mode == L.RESET_MT19937
+    assert np.array_equal(env.reset().cpu().numpy(), ov.reset())
+    acts = splitmix_actions(6, T, n, 2)
+    for t in range(T):
+        s = env.step(torch.from_numpy(acts[t]).cuda())
+        r = ov.step(acts[t])
+        if t % 10 == 0 or t == T - 1:
+            assert np.array_equal(s.observation.cpu().numpy(), r["obs"]), t
+            assert np.array_equal(s.done.cpu().numpy()[:, 0], r["done"]), t
+        if t == 900 and seed is not None:
+            env.seed(seed + 1); ov.seed(seed + 1)       # VecEnv::seed mid-run: every generator restarts (env.h:60-63)
+    assert env.engine.poll_error() == 0 and int(env.engine.counters()["cursor"].min()) >= (190 if seed is not None else 480)
