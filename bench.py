@@ -425,13 +425,15 @@ def main():
         return {"kernel_ms": round(ms, 4), "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "note": "not `value`: a 512 MiB cache sweep runs between the steps; the step kernel alone is timed"}
 
-    def measure_config3(n3, steps):
+    def measure_config3(n3, steps, form="moments"):
         """BASELINE configs[2]: MountainCar + TimeLimit(200) + ClipReward + Monitor + obs/return normaliser; with more than one
         rank the per-step batch moments + episode statistics (12 doubles) are all-reduced over RCCL between the step and the
         normalise kernels.  n3 envs PER GPU."""
         w = (L.WRAP_TIME_LIMIT | L.WRAP_CLIP_REWARD | L.WRAP_MONITOR | L.WRAP_NORM_OBS | L.WRAP_NORM_REWARD | L.WRAP_NORM_TRAINING)
         eng = Engine(EngineConfig(env_kind=L.ENV_MOUNTAINCAR, n_envs=n3, precision=L.PRECISION_LOCKSTEP_F64, reset_mode=L.RESET_COUNTER_RNG,
                                   wrappers=w, max_episode_steps=200, env_offset=rank * n3), local_rank)
+        if world > 1 and form == "rows":
+            eng.set_exchange_form(L.EXCHANGE_ROWS)   # no reduce launch: the partial rows themselves are all-reduced (gymhip.h)
 
         def do_reset():
             if world > 1:
@@ -472,7 +474,7 @@ def main():
         if world > 1:
             # Self-check of the exchange (no multi-rank RCCL run exists before the 8-GPU box sees this): the all-reduced batch count must be
             # the sum of the ranks' env counts and the replicated statistics bit-identical on every rank.  A failure fails the run.
-            ok, why = verify_replicated(torch, dist, float(eng.moments[0].item()), n3, stats)
+            ok, why = verify_replicated(torch, dist, float(eng.moments[0 if form == "moments" else 15].item()), n3, stats)
             out["allreduce_verified"], out["allreduce_check"] = ok, why
             if not ok:
                 failures.append(f"config 3 at {n3} envs/GPU: {why}")
@@ -497,7 +499,7 @@ def main():
         bps = 16 + 16 + 4 + 8 + 8 + 4 + 4 + (8 + 8 + 4 + 4)   # step kernel 60 B + normalise kernel 24 B
         out.update({"value": world * n3 * steps / dt, "unit": "env-steps/s", "envs_per_gpu": n3, "ms_per_step": round(dt / steps * 1e3, 4),
                     "bytes_per_env_step": bps, "achieved_GBs": round(bps * n3 * steps / dt / 1e9, 1), "frac": round(bps * n3 * steps / dt / 1e9 / HBM_PEAK_GBS, 4),
-                    "collective": f"all_reduce({eng.moments_len} x f64)/step, backend {backend}" if world > 1 else None, "obs_count": float(stats[4])})
+                    "collective": f"all_reduce({eng.moments_len} x f64)/step, backend {backend}, exchange form {form}" if world > 1 else None, "obs_count": float(stats[4])})
         return out
 
     def measure_config2():
@@ -771,6 +773,8 @@ def main():
         guarded("config2_cartpole_lockstep_65536", measure_config2)
         guarded("cartpole_lockstep_rollout_32_steps_per_launch", measure_rollout_big)
         guarded("config3_mountaincar_vecnormalize_131072_per_gpu", measure_config3, 1 << 17, max(args.steps, 500))   # configs[2]'s per-GPU shard on 8 GPUs
+        if world > 1:   # the exchange form without the reduce launch (32 KB payload): measured next to the default on every multi-rank run
+            guarded("config3_mountaincar_vecnormalize_131072_per_gpu_rows_exchange", measure_config3, 1 << 17, max(args.steps, 500), "rows")
         guarded("config3_mountaincar_vecnormalize_1M_per_gpu", measure_config3, 1 << 20, max(args.steps, 200))
         guarded("config3_mountaincar_vecnormalize_16M_per_gpu", measure_config3, 1 << 24, max(20, args.steps // 4))
         if rank == 0:

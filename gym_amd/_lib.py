@@ -14,6 +14,7 @@ OK = 0
 ENV_CARTPOLE, ENV_MOUNTAINCAR = 0, 1
 PRECISION_LOCKSTEP_F64, PRECISION_F32 = 0, 1
 RESET_TAPE, RESET_COUNTER_RNG, RESET_MT19937 = 0, 1, 2
+EXCHANGE_MOMENTS, EXCHANGE_ROWS = 0, 1
 WRAP_TIME_LIMIT, WRAP_CLIP_REWARD, WRAP_MONITOR = 1, 2, 4
 WRAP_NORM_OBS, WRAP_NORM_REWARD, WRAP_NORM_TRAINING = 8, 16, 32
 WRAP_NO_AUTO_RESET = 64
@@ -123,6 +124,7 @@ SIGNATURES = {
     "gymhip_atari_reset_indexed": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_step_indexed": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gymhip_launch_info": (C.c_int, [_vp, _vp]),
+    "gymhip_set_exchange_form": (C.c_int, [_vp, C.c_int]),
     "gymhip_atari_push_reset": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_push": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gymhip_atari_materialize_nhwc": (C.c_int, [_vp, _vp, _vp]),

@@ -633,6 +633,17 @@ __global__ __launch_bounds__(kFoldThreads) void reduce_partials_kernel(const dou
     if (threadIdx.x == 0) moments[0] = n_local;
 }
 
+// ROWS exchange form (gymhip_set_exchange_form): the ranks all-reduce the partial ROWS themselves — [pad_rows][kMaxCols] doubles,
+// tens of KB, still latency-bound — and the normalise kernel folds the summed rows in its prologue, as it does on a single GPU: no
+// reduce launch between the step and the collective.  For that the payload must be self-contained: the last column of row 0 carries
+// this rank's env count (the other rows' last column is 0), and rows [gridDim.x, pad_rows) — which no block of this launch owns but
+// an earlier Updateable::update pass may have used — are zeroed.  Thread c < kMaxCols of every block.
+__device__ inline void publish_row_padding(const StepParams& p, int c) {
+    if (p.pad_rows <= 0 || c >= kMaxCols) return;
+    if (c == kMaxCols - 1) p.partials[(int64_t)blockIdx.x * kMaxCols + c] = blockIdx.x == 0 ? (double)p.n : 0.0;
+    for (int r = blockIdx.x + gridDim.x; r < p.pad_rows; r += gridDim.x) p.partials[(int64_t)r * kMaxCols + c] = 0.0;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Kernel A: one VecEnv::step for every env.
 // ------------------------------------------------------------------------------------------------------------
@@ -783,6 +794,7 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
             // cumulative per-block episode counters (owner-block read-modify-write: no atomics, deterministic)
             if (c >= 2 * F + 2) p.ep_partials[(int64_t)blockIdx.x * 4 + (c - (2 * F + 2))] += t;
         }
+        publish_row_padding(p, c);
     } else {
         block_reduce_store<3>(ep, p.ep_partials + (int64_t)blockIdx.x * 4, true);
     }
@@ -841,6 +853,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const StepParams p) {
         for (int c = 0; c < 2 * F + 2; c++) cols[c] = acc[c];
         cols[2 * F + 2] = 0; cols[2 * F + 3] = 0; cols[2 * F + 4] = 0;
         block_reduce_store<2 * F + 5>(cols, p.partials + (int64_t)blockIdx.x * kMaxCols, false);
+        publish_row_padding(p, threadIdx.x);
     }
 }
 
@@ -903,9 +916,10 @@ __global__ __launch_bounds__(kBlock) void normalize_kernel(const NormParams q) {
     __shared__ double fold_red[16][kMaxCols];
     __shared__ double mom[kMaxCols];
     if (q.partials) {
-        const double tot = fold_partial_rows(q.partials, q.rows, 2 * F + 5, fold_red, threadIdx.x);
+        const double tot = fold_partial_rows(q.partials, q.rows, q.n_from_rows ? kMaxCols : 2 * F + 5, fold_red, threadIdx.x);
         if ((int)threadIdx.x < 2 * F + 5) { mom[1 + threadIdx.x] = tot; if (blockIdx.x == 0) q.moments_out[1 + threadIdx.x] = tot; }
-        if (threadIdx.x == 0) { mom[0] = q.n_local; if (blockIdx.x == 0) q.moments_out[0] = q.n_local; }
+        if (q.n_from_rows) { if (threadIdx.x == kMaxCols - 1) { mom[0] = tot; if (blockIdx.x == 0) q.moments_out[0] = tot; } }   // all ranks' env counts, summed by the all-reduce
+        else if (threadIdx.x == 0) { mom[0] = q.n_local; if (blockIdx.x == 0) q.moments_out[0] = q.n_local; }
     } else if ((int)threadIdx.x < 2 * F + 6) {
         mom[threadIdx.x] = q.moments[threadIdx.x];
     }
@@ -1305,6 +1319,7 @@ struct gymhip_engine {
     bool stream_nt;          // step kernel streams with non-temporal accesses (footprint beyond the Infinity Cache)
     int keep_small;          // residency plan of an NT engine (plan_residency): the 4-B lanes that stay in the Infinity Cache, one of kPlans
     double* scratch_dev;     // this device's copy of the static `scratch` array (resolve_scratch)
+    int exchange_form;       // GYMHIP_EXCHANGE_MOMENTS (reduce launch, 2F+6 doubles) | GYMHIP_EXCHANGE_ROWS (the partial rows themselves)
     bool mt;                 // CartPole with per-env std::mt19937 states on the device (GYMHIP_RESET_MT19937)
 
     template <typename T> T* at(size_t off) const { return off == (size_t)-1 ? nullptr : (T*)(ws + off); }
@@ -1340,6 +1355,10 @@ void plan_residency(gymhip_engine* h) {
     }
 }
 
+// Partial rows of the ROWS exchange payload: the engine's grid rounded up to a size every rank with (nearly) the same env count
+// agrees on — 256 (one round trip of the fold) or kDefaultGrid.
+int exchange_rows(const gymhip_engine* h) { return h->grid <= 256 ? 256 : kDefaultGrid; }
+
 StepParams make_params(gymhip_engine* h) {
     StepParams p{};
     p.n = h->cfg.n_envs;
@@ -1351,6 +1370,7 @@ StepParams make_params(gymhip_engine* h) {
     p.reset_mode = h->cfg.reset_mode;
     p.gamma = h->cfg.gamma;
     p.lanes = h->lanes;
+    p.pad_rows = (h->norm && h->exchange_form == GYMHIP_EXCHANGE_ROWS) ? exchange_rows(h) : 0;
     p.error_flag = h->at<int32_t>(h->L.error_flag);
     p.partials = h->at<double>(h->L.partials);
     p.ep_partials = h->at<double>(h->L.ep_partials);
@@ -1471,7 +1491,7 @@ void launch_reduce_partials(gymhip_engine* h, hipStream_t s) {
                        (double)h->cfg.n_envs, h->at<double>(h->L.moments));
 }
 
-int launch_normalize(gymhip_engine* h, bool is_reset, hipStream_t s, bool fold) {
+int launch_normalize(gymhip_engine* h, bool is_reset, hipStream_t s, bool fold, bool rows_form = false) {
     const uint32_t w = h->cfg.wrappers;
     const bool training = w & GYMHIP_WRAP_NORM_TRAINING;
     NormParams q{};
@@ -1480,6 +1500,7 @@ int launch_normalize(gymhip_engine* h, bool is_reset, hipStream_t s, bool fold) 
     q.tick_w = h->at<int32_t>(h->L.ticks); q.tick_r = h->at<int32_t>(h->L.ticks) + 1;
     q.moments = h->at<double>(h->L.moments);
     if (fold) { q.partials = h->at<double>(h->L.partials); q.rows = h->grid; q.n_local = (double)h->cfg.n_envs; q.moments_out = h->at<double>(h->L.moments); }
+    if (rows_form) { q.rows = exchange_rows(h); q.n_from_rows = true; }   // the rows were summed over ranks by the caller's all-reduce
     q.ep_totals_global = is_reset ? nullptr : h->at<double>(h->L.ep_totals_global);
     q.obs = h->at<float>(h->L.obs);
     q.obs_norm = h->at<float>(h->L.obs_norm);
@@ -1532,6 +1553,7 @@ int gymhip_create(const gymhip_config* cfg, int device, void* workspace, size_t 
     h->tape = nullptr; h->tape_episodes = 0; h->tape_source = 0; h->tape_seeded = false; h->tape_seed = 0;
     h->did_reset = false; h->pending_finish = false; h->pending_is_reset = false;
     h->mt = cfg->env_kind == KIND_CARTPOLE && cfg->reset_mode == GYMHIP_RESET_MT19937;
+    h->exchange_form = GYMHIP_EXCHANGE_MOMENTS;
     // Plain (temporal) accesses win while everything a step touches stays in the 256 MiB Infinity Cache from one step to the next;
     // beyond that they thrash it and the engine streams non-temporally under a residency plan (plan_residency).  "Everything" is
     // the workspace plus the callers' action rows — the bench rotates four int32 rows, a trainer's policy has its own traffic — so
@@ -1595,6 +1617,7 @@ int gymhip_get_buffers(gymhip_engine* h, gymhip_buffers* out) {
     out->returns = h->at<float>(h->L.returns);
     out->norm_stats = h->norm ? h->stats_slot_ptr(2) : nullptr;
     out->moments = h->at<double>(h->L.moments);
+    if (h->norm && h->exchange_form == GYMHIP_EXCHANGE_ROWS) { out->moments = h->at<double>(h->L.partials); out->moments_len = exchange_rows(h) * kMaxCols; }
     out->episode_totals = h->at<double>(h->L.ep_totals);
     out->mt_state = h->at<uint32_t>(h->L.mt_state);
     return GYMHIP_OK;
@@ -1742,8 +1765,8 @@ static int reset_begin_impl(gymhip_engine* h, void* stream, bool split) {
     StepParams p = make_params(h);
     if (h->cfg.env_kind == KIND_CARTPOLE) launch_reset_kind<KIND_CARTPOLE>(h, p, s); else launch_reset_kind<KIND_MOUNTAINCAR>(h, p, s);
     if (h->norm) {
-        if (split) launch_reduce_partials(h, s);         // the totals are the all-reduce payload
-        else launch_normalize(h, true, s, true);         // unsplit: the normalise kernel folds the partial rows itself
+        if (!split) launch_normalize(h, true, s, true);                                   // unsplit: the normalise kernel folds the partial rows itself
+        else if (h->exchange_form == GYMHIP_EXCHANGE_MOMENTS) launch_reduce_partials(h, s);   // the totals are the all-reduce payload (ROWS: the rows are)
     }
     HIP_TRY(hipGetLastError());
     h->did_reset = true;
@@ -1763,8 +1786,8 @@ static int step_begin_impl(gymhip_engine* h, const void* actions, int action_dty
     p.actions = actions;
     if (h->cfg.env_kind == KIND_CARTPOLE) launch_step_kind<KIND_CARTPOLE>(h, p, action_dtype, s); else launch_step_kind<KIND_MOUNTAINCAR>(h, p, action_dtype, s);
     if (h->norm) {
-        if (split) launch_reduce_partials(h, s);
-        else launch_normalize(h, false, s, true);
+        if (!split) launch_normalize(h, false, s, true);
+        else if (h->exchange_form == GYMHIP_EXCHANGE_MOMENTS) launch_reduce_partials(h, s);
     }
     HIP_TRY(hipGetLastError());
     h->pending_finish = h->norm && split; h->pending_is_reset = false;
@@ -1776,7 +1799,8 @@ static int finish_common(gymhip_engine* h, bool is_reset, void* stream) {
     if (int rc = check_handle(h)) return rc;
     if (!h->norm) return GYMHIP_OK;
     if (!h->pending_finish || h->pending_is_reset != is_reset) return fail(GYMHIP_ESTATE, "*_finish without the matching *_begin");
-    launch_normalize(h, is_reset, (hipStream_t)stream, false);
+    const bool rows_form = h->exchange_form == GYMHIP_EXCHANGE_ROWS;
+    launch_normalize(h, is_reset, (hipStream_t)stream, rows_form, rows_form);
     HIP_TRY(hipGetLastError());
     h->pending_finish = false;
     return GYMHIP_OK;
@@ -1862,6 +1886,15 @@ int gymhip_poll_error(gymhip_engine* h, int32_t* host_out, void* stream) {
     if (!host_out) return fail(GYMHIP_EINVAL, "host_out is null");
     HIP_TRY(hipMemcpyAsync(host_out, h->at<int32_t>(h->L.error_flag), 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return GYMHIP_OK;
+}
+
+int gymhip_set_exchange_form(gymhip_engine* h, int form) {
+    if (int rc = check_handle(h)) return rc;
+    if (form != GYMHIP_EXCHANGE_MOMENTS && form != GYMHIP_EXCHANGE_ROWS) return fail(GYMHIP_EINVAL, "unknown exchange form %d", form);
+    if (!h->norm) return fail(GYMHIP_EINVAL, "engine has no normaliser: nothing is exchanged");
+    if (h->pending_finish) return fail(GYMHIP_ESTATE, "previous *_begin has no matching *_finish");
+    h->exchange_form = form;
     return GYMHIP_OK;
 }
 

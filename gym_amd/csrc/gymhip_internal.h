@@ -42,6 +42,8 @@ struct StepParams {
     int32_t max_episode_steps;
     int32_t reset_mode;
     float gamma;
+    int32_t pad_rows;        // ROWS exchange form: the all-reduce payload is partial rows [0, pad_rows); the step / reset kernel writes this
+                             // rank's env count into row 0's last column and zeroes every row its own blocks do not own (0 = off)
     int32_t lanes;           // threads of each workgroup that own envs (a multiple of 64, <= the block size): small env counts are spread
                              // over more workgroups than n / block would give, so that every CU gets one (the rest of the block idles)
     StepBuffers buf;
@@ -56,6 +58,7 @@ struct NormParams {
     const double* partials;  // unsplit step: the step kernel's per-block rows [rows][16], folded in the kernel's prologue
     int rows;
     double n_local;
+    bool n_from_rows;        // ROWS exchange form: the batch count is the folded total of the rows' last column (summed over ranks)
     double* moments_out;     // unsplit step: block 0 publishes the folded moments here (the engine's `moments` buffer)
     double* ep_totals_global;
     const float* obs;

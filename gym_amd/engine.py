@@ -177,6 +177,15 @@ class Engine:
         self._keep = a
         L.check(self.lib.gymhip_step_begin(self.h, C.c_void_p(a.data_ptr()), _ACT_DTYPES[a.dtype], self._stream()), "gymhip_step_begin")
 
+    def set_exchange_form(self, form: int):
+        """What `moments` holds between *_begin and *_finish: L.EXCHANGE_MOMENTS (2F+6 doubles after a reduce launch) or
+        L.EXCHANGE_ROWS (the per-block partial rows themselves; no reduce launch).  Re-points `self.moments`."""
+        L.check(self.lib.gymhip_set_exchange_form(self.h, form), "gymhip_set_exchange_form")
+        b = L.Buffers()
+        L.check(self.lib.gymhip_get_buffers(self.h, C.byref(b)), "gymhip_get_buffers")
+        self.moments_len = b.moments_len
+        self.moments = self._view(b.moments, torch.float64, (self.moments_len,))
+
     def step_finish(self):
         L.check(self.lib.gymhip_step_finish(self.h, self._stream()), "gymhip_step_finish")
 

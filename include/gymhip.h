@@ -172,6 +172,16 @@ int gymhip_step(gymhip_engine* h, const void* actions, int action_dtype, void* s
  * which applies RunningMeanStd::updateFromMoment (running_mean_std.h:46-66) and normalises.  The same split exists
  * for reset. */
 int gymhip_step_begin(gymhip_engine* h, const void* actions, int action_dtype, void* stream);
+/* What the ranks exchange between _begin and _finish (normaliser engines; gymhip_get_buffers reports `moments` / `moments_len`
+ * for the form in force — call it again after switching):
+ *   GYMHIP_EXCHANGE_MOMENTS (default): _begin ends with a one-block reduce launch; the payload is 2F+6 doubles (80 - 112 B).
+ *   GYMHIP_EXCHANGE_ROWS: no reduce launch — the payload is the step kernel's per-block partial rows themselves, f64
+ *     [256 or 512][16] (32 / 64 KB, still latency-bound on xGMI), row 0 carrying this rank's env count; _finish folds the
+ *     summed rows in the normalise kernel's prologue, as the single-GPU step does.  One launch fewer per step.  Every rank must
+ *     use the same form and report the same `moments_len` (they do when their env counts are within the same size class).
+ * No reference counterpart (the reference has no collective). */
+enum { GYMHIP_EXCHANGE_MOMENTS = 0, GYMHIP_EXCHANGE_ROWS = 1 };
+int gymhip_set_exchange_form(gymhip_engine* h, int form);
 int gymhip_step_finish(gymhip_engine* h, void* stream);
 int gymhip_reset_begin(gymhip_engine* h, void* stream);
 int gymhip_reset_finish(gymhip_engine* h, void* stream);

@@ -179,6 +179,27 @@ def test_cpp_rccl_allreduce_binding_on_the_moments_buffer():
     tag, same, _, steps, _, count = line.split()
     assert same == "1" and int(steps) == T
     assert float(count) > n * T                                                               # the statistics moved: (T+1) batches of n rows
+    forms = {l.split()[1]: dict(zip(l.split()[2::2], l.split()[3::2])) for l in r.stdout.splitlines() if l.startswith("rccl_form")}
+    assert forms["moments"]["stats_bit_identical"] == "1" and forms["moments"]["payload_bytes"] == "80"
+    # the exchange form without the reduce launch: the partial rows themselves are all-reduced (32 KB here), raw streams identical
+    assert forms["rows"]["raw_identical"] == "1" and forms["rows"]["replicated"] == "1" and forms["rows"]["payload_bytes"] == str(256 * 16 * 8)
+    assert float(forms["rows"]["worst_stat_rel"]) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_cpp_rccl_demo_takes_a_rank_count_and_refuses_more_gpus_than_are_visible():
+    """The N-rank form of the call sequence: `rccl_moments_demo n steps N` drives N GPUs from one process (ncclCommInitAll, one
+    group call per exchange) against one engine that holds all N n envs.  This box has one GPU: N = 1 runs, N = 99 must fail
+    with its own exit code instead of quietly running fewer ranks; the timing leg (eager / HIP graph with the RCCL call inside /
+    unsplit) prints one line per exchange form."""
+    exe = os.path.join(ROOT, "tests", "cpp", "bin", "rccl_moments_demo")
+    r = subprocess.run([exe, "4096", "5", "99"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 6 and "asked for 99 GPUs" in r.stderr
+    r = subprocess.run([exe, "131072", "5", "1", "300"], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    times = [dict(zip(l.split()[1::2], l.split()[2::2])) for l in r.stdout.splitlines() if l.startswith("rccl_time")]
+    assert [t["form"] for t in times] == ["moments", "rows"] and all(t["ranks"] == "1" and float(t["eager_us"]) > 0 for t in times)
+    print("\n".join(l for l in r.stdout.splitlines() if l.startswith("rccl_")))
 
 
 @pytest.mark.gpu

@@ -110,15 +110,24 @@ def test_first_normalised_rewards_match_reference_probe(oracle):
     assert np.allclose(eng.reward.cpu().numpy(), 2.02, atol=5e-3)
 
 
-def test_sharded_moments_allreduce_equals_single_engine(oracle):
+@pytest.mark.parametrize("form,n", [("moments", 16384), ("rows", 16384), ("rows", 600_000), ("rows", 3000)])
+def test_sharded_moments_allreduce_equals_single_engine(oracle, form, n):
     """Two engines holding the two halves of the env range, with the `moments` payloads summed between
     step_begin and step_finish (what the RCCL all-reduce does across ranks), must track the single-engine run:
-    raw streams exactly, running statistics to 1e-6, normalised outputs to 1e-5 (conditioning-scaled)."""
+    raw streams exactly, running statistics to 1e-6, normalised outputs to 1e-5 (conditioning-scaled).
+    "rows": the exchange form without the reduce launch (gymhip_set_exchange_form) — the payload is the partial rows themselves
+    (row 0 carries each rank's env count), padded to 256 or 512 rows whatever the engine's grid is; an Updateable::update pass in
+    between (which borrows the same rows) must not leak into the next step's payload."""
     from gym_amd import _lib as L
-    n, T = 16384, 260
+    T = 260 if n <= 16384 else 40
     w = L.WRAP_TIME_LIMIT | L.WRAP_CLIP_REWARD | L.WRAP_MONITOR | _norm_flags()
     one = _engine(L.ENV_MOUNTAINCAR, n, w, 200)
     halves = [_engine(L.ENV_MOUNTAINCAR, n // 2, w, 200, env_offset=k * n // 2) for k in range(2)]
+    if form == "rows":
+        for h in halves:
+            h.set_exchange_form(L.EXCHANGE_ROWS)
+            assert h.moments.numel() in (256 * 16, 512 * 16)
+        assert halves[0].moments.numel() == halves[1].moments.numel()
 
     def allreduce():
         tot = halves[0].moments + halves[1].moments
@@ -137,9 +146,15 @@ def test_sharded_moments_allreduce_equals_single_engine(oracle):
         for k, h in enumerate(halves):
             h.step_begin(acts[t, k * n // 2:(k + 1) * n // 2])
         allreduce()
-        assert float(halves[0].moments[0]) == n          # global batch count
+        assert float(halves[0].moments[0 if form == "moments" else 15]) == n          # global batch count
         for h in halves:
             h.step_finish()
+        if form == "rows" and t == 20:
+            # Updateable::update borrows the partial rows (more of them than the step kernel owns at small n)
+            g_ = torch.Generator(device="cuda").manual_seed(0)
+            rows = torch.randn((300_001, 2), device="cuda", generator=g_) * 0.1 - 0.4
+            for e in [one] + halves:
+                e.update_norm_stats(rows, None)
         s1 = one.get_norm_stats()
         for k, h in enumerate(halves):
             sl = slice(k * n // 2, (k + 1) * n // 2)
