@@ -127,6 +127,7 @@ SIGNATURES = {
     "gymhip_set_exchange_form": (C.c_int, [_vp, C.c_int]),
     "gymhip_atari_push_reset": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_push": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "gymhip_atari_push_index": (C.c_int, [_vp, _i64, _vp, C.c_int, _vp]),
     "gymhip_atari_materialize_nhwc": (C.c_int, [_vp, _vp, _vp]),
     "gymhip_atari_set_stack_view": (C.c_int, [_vp, C.c_int]),
     "gymhip_atari_materialize_nchw_f32": (C.c_int, [_vp, _vp, _vp]),

@@ -277,12 +277,32 @@ __global__ __launch_bounds__(kBlock) void push_planes_kernel(const uint32_t* __r
     }
 }
 
+// One plane for one env, or for all of them (gymhip_atari_push_index).  `only_env` >= 0: that env starts over — its other slots are
+// zeroed and the plane becomes its newest frame, nobody else is touched.  `only_env` < 0: the same plane goes into slot `slot` of
+// EVERY env (the reference's VecFrameStack::reset(int) as written: a [H, W, 1] frame broadcast over the batch).
+__global__ __launch_bounds__(kBlock) void push_one_plane_kernel(const uint32_t* __restrict__ plane, uint8_t* ring, int64_t n, int plane4, int k, int slot, int64_t only_env) {
+    const int64_t lo = only_env >= 0 ? only_env : blockIdx.x, hi = only_env >= 0 ? only_env + 1 : n, step = only_env >= 0 ? 1 : gridDim.x;
+    if (only_env >= 0 && blockIdx.x != 0) return;
+    for (int64_t e = lo; e < hi; e += step) {
+        uint32_t* env0 = (uint32_t*)ring + e * k * (int64_t)plane4;
+        for (int i = threadIdx.x; i < plane4; i += kBlock) env0[(int64_t)slot * plane4 + i] = plane[i];
+        if (only_env >= 0) {
+            for (int s = 0; s < k; s++) {
+                if (s == slot) continue;
+                for (int i = threadIdx.x; i < plane4; i += kBlock) env0[(int64_t)s * plane4 + i] = 0u;
+            }
+        }
+    }
+}
+
 // ring u8 [N][k][P] (slot `head` newest) -> NHWC u8 [N][P][k], channel c = (head + 1 + c) % k (oldest first).
-__global__ __launch_bounds__(kBlock) void materialize_nhwc_kernel(const uint8_t* ring, uint8_t* out, int64_t n, int P, int k, int head) {
+// `packed`: out is 4-byte aligned, so the four channels of a pixel may go out as one dword (host-side check; a byte view at an odd
+// offset takes the byte path).
+__global__ __launch_bounds__(kBlock) void materialize_nhwc_kernel(const uint8_t* ring, uint8_t* out, int64_t n, int P, int k, int head, bool packed) {
     const int64_t total = n * (int64_t)P;
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < total; j += (int64_t)gridDim.x * kBlock) {
         const int64_t e = j / P; const int px = (int)(j - e * P);
-        if (k == 4) {
+        if (k == 4 && packed) {
             uint32_t w = 0;
 #pragma unroll
             for (int c = 0; c < 4; c++) w |= (uint32_t)ring[(e * 4 + ((head + 1 + c) & 3)) * (int64_t)P + px] << (8 * c);
@@ -329,13 +349,13 @@ __global__ __launch_bounds__(kBlock) void materialize_nhwc4_kernel(const uint8_t
 
 // The reference's stack AS WRITTEN (gymhip.h): channel 0 = plane `first_slot` of the ring (or zeros when first_slot < 0),
 // channels 1 .. k-1 = the newest plane.
-__global__ __launch_bounds__(kBlock) void materialize_nhwc_as_written_kernel(const uint8_t* ring, uint8_t* out, int64_t n, int P, int k, int head, int first_slot) {
+__global__ __launch_bounds__(kBlock) void materialize_nhwc_as_written_kernel(const uint8_t* ring, uint8_t* out, int64_t n, int P, int k, int head, int first_slot, bool packed) {
     const int64_t total = n * (int64_t)P;
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < total; j += (int64_t)gridDim.x * kBlock) {
         const int64_t e = j / P; const int px = (int)(j - e * P);
         const uint32_t newest = ring[(e * k + head) * (int64_t)P + px];
         const uint32_t first = first_slot < 0 ? 0u : ring[(e * k + first_slot) * (int64_t)P + px];
-        if (k == 4) {
+        if (k == 4 && packed) {
             ((uint32_t*)out)[j] = first | (newest << 8) | (newest << 16) | (newest << 24);
         } else {
             out[j * k] = (uint8_t)first;
@@ -699,6 +719,25 @@ static int push_any(gymhip_atari* h, const uint8_t* planes, const uint8_t* done,
 int gymhip_atari_push_reset(gymhip_atari* h, const uint8_t* planes, void* stream) { return push_any(h, planes, nullptr, true, stream); }
 int gymhip_atari_push(gymhip_atari* h, const uint8_t* planes, const uint8_t* done, void* stream) { return push_any(h, planes, done, false, stream); }
 
+int gymhip_atari_push_index(gymhip_atari* h, int64_t index, const uint8_t* plane, int as_written, void* stream) {
+    if (int rc = check_atari(h)) return rc;
+    if (!plane || ((uintptr_t)plane % 4)) return fail(GYMHIP_EINVAL, "plane is null or not 4-byte aligned");
+    if (index < 0 || index >= h->cfg.n_envs) return fail(GYMHIP_EINVAL, "env index %lld out of range [0, %lld)", (long long)index, (long long)h->cfg.n_envs);
+    if (!h->did_reset) return fail(GYMHIP_ESTATE, "atari push_index before reset");
+    const int64_t plane_bytes = (int64_t)h->cfg.dst_h * h->cfg.dst_w;
+    hipStream_t s = (hipStream_t)stream;
+    if (as_written) {   // StackedObservation::update over ONE env's frame: every stack shifts, the frame is broadcast (vec_frame_stack.cpp:34-37)
+        h->updates_since_reset++;
+        h->head = (h->head + 1) % h->cfg.n_stack;
+        const unsigned grid = (unsigned)std::min<int64_t>(h->cfg.n_envs, 1 << 16);
+        hipLaunchKernelGGL(push_one_plane_kernel, dim3(grid), dim3(kBlock), 0, s, (const uint32_t*)plane, h->ring, (int64_t)h->cfg.n_envs, (int)(plane_bytes / 4), h->cfg.n_stack, h->head, (int64_t)-1);
+    } else {
+        hipLaunchKernelGGL(push_one_plane_kernel, dim3(1), dim3(kBlock), 0, s, (const uint32_t*)plane, h->ring, (int64_t)h->cfg.n_envs, (int)(plane_bytes / 4), h->cfg.n_stack, h->head, index);
+    }
+    HIP_TRY(hipGetLastError());
+    return GYMHIP_OK;
+}
+
 int gymhip_atari_set_stack_view(gymhip_atari* h, int view) {
     if (int rc = check_atari(h)) return rc;
     if (view != GYMHIP_STACK_INTENDED && view != GYMHIP_STACK_AS_WRITTEN) return fail(GYMHIP_EINVAL, "view must be GYMHIP_STACK_INTENDED or GYMHIP_STACK_AS_WRITTEN");
@@ -725,9 +764,9 @@ int gymhip_atari_materialize_nhwc(gymhip_atari* h, uint8_t* out, void* stream) {
         if (ring_bytes <= kRingKeepBytes / 2) hipLaunchKernelGGL(materialize_nhwc4_kernel<false>, dim3(grid), dim3(kBlock), 0, s, h->ring, out, (int64_t)h->cfg.n_envs, P4, split, s0, s1, s2, hd);
         else hipLaunchKernelGGL(materialize_nhwc4_kernel<true>, dim3(grid), dim3(kBlock), 0, s, h->ring, out, (int64_t)h->cfg.n_envs, P4, split, s0, s1, s2, hd);
     } else if (first == kViewIntended) {
-        hipLaunchKernelGGL(materialize_nhwc_kernel, dim3(2048), dim3(kBlock), 0, s, h->ring, out, h->cfg.n_envs, P, k, h->head);
+        hipLaunchKernelGGL(materialize_nhwc_kernel, dim3(2048), dim3(kBlock), 0, s, h->ring, out, h->cfg.n_envs, P, k, h->head, ((uintptr_t)out & 3) == 0);
     } else {
-        hipLaunchKernelGGL(materialize_nhwc_as_written_kernel, dim3(2048), dim3(kBlock), 0, s, h->ring, out, h->cfg.n_envs, P, k, h->head, first);
+        hipLaunchKernelGGL(materialize_nhwc_as_written_kernel, dim3(2048), dim3(kBlock), 0, s, h->ring, out, h->cfg.n_envs, P, k, h->head, first, ((uintptr_t)out & 3) == 0);
     }
     HIP_TRY(hipGetLastError());
     return GYMHIP_OK;

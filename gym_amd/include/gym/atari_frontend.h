@@ -59,6 +59,8 @@ struct AtariFrontEndOptions {
                                         // cv::max (atari_wrappers.cpp:30) yields the LAST emulated frame.
     bool stack_as_written = false;      // true = gymhip_atari_set_stack_view(GYMHIP_STACK_AS_WRITTEN): VecFrameStack + VecNormAndPermute as the
                                         // reference computes them today ([prev, new, new, new] channels, signed bytes / 255; gymhip.h)
+    bool reset_index_as_written = false;   // reset(int index) as the reference's VecFrameStack has it: every stack shifts, the one frame is
+                                        // broadcast over the batch (vec_frame_stack.cpp:34-37); default: only that env's stack starts over
     int n_stack = 4;                    // VecFrameStack
     int src_h = 210, src_w = 160, dst_h = 84, dst_w = 84;
     int device = 0;
@@ -93,6 +95,7 @@ public:
         c.n_stack = opt.n_stack; c.gray_bits = 15; c.clear_on_done = 0;
         if (gymhip_atari_create(&c, opt.device, &pp) != GYMHIP_OK) throw std::runtime_error(gymhip_last_error());
         if (gymhip_atari_set_palette(pp, zrgb256_palette) != GYMHIP_OK) throw std::runtime_error(gymhip_last_error());
+        palette.assign(zrgb256_palette, zrgb256_palette + 256);
         if (opt.stack_as_written && gymhip_atari_set_stack_view(pp, GYMHIP_STACK_AS_WRITTEN) != GYMHIP_OK) throw std::runtime_error(gymhip_last_error());
         const size_t bytes = (size_t)n * 2 * hw;
         check(hipHostMalloc((void**)&staging, bytes, hipHostMallocDefault), "hipHostMalloc");
@@ -106,6 +109,8 @@ public:
         (void)hipSetDevice(opt.device);
         (void)hipDeviceSynchronize();
         if (pp) gymhip_atari_destroy(pp);
+        if (pp_one) gymhip_atari_destroy(pp_one);
+        if (dev_plane_one) (void)hipFree(dev_plane_one);
         if (staging) (void)hipHostFree(staging);
         if (dev_screens) (void)hipFree(dev_screens);
         if (dev_obs) (void)hipFree(dev_obs);
@@ -130,6 +135,32 @@ public:
         if (gymhip_atari_reset_indexed(pp, dev_screens, stream) != GYMHIP_OK) throw std::runtime_error(gymhip_last_error());
         check(hipEventRecord(consumed, stream), "hipEventRecord"); have_consumed = true;
         materialize(stream);
+    }
+
+    // VecEnv::reset(int index) (sync_env.h:128-139 under VecFrameStack / VecNormAndPermute): env i alone runs its outermost reset on
+    // the host; its two screens go up, a one-env preprocessor (same palette, same kernels) turns them into the 84x84 plane, and that
+    // plane enters the ring through gymhip_atari_push_index — by default into env i's stack only, which starts over.
+    void reset_index(int64_t i, hipStream_t stream = nullptr) {
+        if (i < 0 || i >= n) throw std::out_of_range("AtariFrontEnd::reset_index");
+        check(hipSetDevice(opt.device), "hipSetDevice");
+        check(hipStreamSynchronize(copy_stream), "hipStreamSynchronize");
+        if (!pp_one) {
+            gymhip_atari_config c{};
+            c.struct_size = sizeof c; c.n_envs = 1; c.src_h = opt.src_h; c.src_w = opt.src_w; c.dst_h = opt.dst_h; c.dst_w = opt.dst_w;
+            c.n_stack = 1; c.gray_bits = 15; c.clear_on_done = 0;
+            if (gymhip_atari_create(&c, opt.device, &pp_one) != GYMHIP_OK || gymhip_atari_set_palette(pp_one, palette.data()) != GYMHIP_OK) throw std::runtime_error(gymhip_last_error());
+            check(hipMalloc((void**)&dev_plane_one, (size_t)opt.dst_h * opt.dst_w), "hipMalloc(plane)");
+        }
+        top_reset(i);
+        reward[i] = 0.f; done[i] = 0; has_episode[i] = 0; lives[i] = envs[i].emu->lives();
+        const size_t off = (size_t)i * 2 * hw;
+        check(hipStreamSynchronize(stream), "hipStreamSynchronize");   // the last step's kernel has read dev_screens
+        check(hipMemcpyAsync(dev_screens + off, staging + off, 2 * hw, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+        if (gymhip_atari_preprocess_indexed(pp_one, dev_screens + off, dev_plane_one, stream) != GYMHIP_OK ||
+            gymhip_atari_push_index(pp, i, dev_plane_one, opt.reset_index_as_written ? 1 : 0, stream) != GYMHIP_OK)
+            throw std::runtime_error(gymhip_last_error());
+        materialize(stream);
+        check(hipStreamSynchronize(stream), "hipStreamSynchronize");   // staging may be rewritten by the next step's emulation
     }
 
     // VecEnv::step(actions): host int actions, one per env
@@ -270,6 +301,9 @@ private:
     size_t hw;
     std::vector<EnvState> envs;
     gymhip_atari* pp = nullptr;
+    gymhip_atari* pp_one = nullptr;   // one-env preprocessor of reset_index (created on first use)
+    uint8_t* dev_plane_one = nullptr;
+    std::vector<uint32_t> palette;
     uint8_t* staging = nullptr;       // pinned u8 [N][2][H][W]
     uint8_t* dev_screens = nullptr;   // device copy
     float* dev_obs = nullptr;

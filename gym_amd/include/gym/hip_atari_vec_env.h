@@ -71,11 +71,18 @@ public:
         return {observation(), reward, done, std::move(info)};
     }
 
-    // The reference's per-index calls on this stack: SyncVecEnv::reset(int) re-runs ONE env's reset chain and VecFrameStack keeps
-    // its stack (vec_frame_stack.h has no per-index override); the fused front-end uploads and preprocesses all envs per launch and
-    // has no single-env path, so the per-index reset is not offered.  step(index, action) is a stub in the reference that returns
-    // the buffered values (sync_env.h:141-157); so does this.
-    torch::Tensor reset(int) override { throw std::runtime_error("HipAtariVecEnv: reset(int index) is not supported by the batched front-end"); }
+    // The reference's per-index calls on this stack.  reset(int index): SyncVecEnv::reset(int) re-runs ONE env's reset chain
+    // (sync_env.h:128-139) and VecFrameStack::reset(int) feeds the single frame to StackedObservation::update (vec_frame_stack.cpp:34-37),
+    // which — as written — shifts every env's stack and broadcasts that frame over the batch.  Default here: env `index` alone starts
+    // over (its stack zeroed, the fresh frame newest) and ITS observation [nStack, 84, 84] is returned; with
+    // AtariFrontEndOptions::reset_index_as_written the reference's behaviour is reproduced and the whole batch is returned.
+    // step(index, action) is a stub in the reference that returns the buffered values (sync_env.h:141-157); so does this.
+    torch::Tensor reset(int index) override {
+        if (!did_reset) throw std::runtime_error("HipAtariVecEnv::reset(int index) before reset()");
+        if (index < 0 || index >= numEnvs) throw std::runtime_error("HipAtariVecEnv::reset(int index): index out of range");
+        fe.reset_index(index, stream);
+        return opt.reset_index_as_written ? observation() : observation()[index];
+    }
     StepT step(int index, torch::Tensor const&) noexcept override {
         if (!last_reward.defined() || index < 0 || index >= numEnvs) return {};
         return {observation()[index], last_reward[index], last_done[index], {last_info[index]}};

@@ -305,6 +305,12 @@ int gymhip_atari_step_indexed(gymhip_atari* h, const uint8_t* screens, const uin
  * The ring, the views and the materialise calls are those of _reset / _step: only the source of the newest plane differs. */
 int gymhip_atari_push_reset(gymhip_atari* h, const uint8_t* planes, void* stream);
 int gymhip_atari_push(gymhip_atari* h, const uint8_t* planes, const uint8_t* done, void* stream);
+/* VecEnv::reset(int index) under VecFrameStack (sync_env.h:128-139 + vec_frame_stack.cpp:34-37): `plane` = the ONE freshly reset env's
+ * dst_h x dst_w image on the device.  as_written = 0 (what a trainer means): env `index` starts over — its stack is zeroed and the
+ * plane becomes its newest frame, as VecFrameStack::reset does for all envs (stacked_observation.h:106-109); the other envs' stacks
+ * are untouched.  as_written = 1: the reference's code as it stands — StackedObservation::update is handed the single [H, W, 1]
+ * frame, so EVERY env's stack shifts by one and that frame is broadcast into every env's newest slot. */
+int gymhip_atari_push_index(gymhip_atari* h, int64_t index, const uint8_t* plane, int as_written, void* stream);
 /* The stacked observation as a contiguous tensor: channels-last u8 [n_envs][dst_h][dst_w][n_stack], oldest frame in
  * channel 0 (what VecFrameStack returns over WarpFrame's {84,84,1} space, stacked_observation.h:96-99,203-209). */
 int gymhip_atari_materialize_nhwc(gymhip_atari* h, uint8_t* out, void* stream);

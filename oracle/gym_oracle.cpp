@@ -836,6 +836,12 @@ void oracle_atari_chain_reset(void* h, uint8_t* frames84) {
     auto* v = (oracle_atari::VecChain*)h;
     for (size_t i = 0; i < v->envs.size(); i++) { auto f = v->envs[i].top->reset(); std::memcpy(frames84 + i * 7056, f.data(), 7056); }
 }
+// SyncVecEnv::reset(int index) (sync_env.h:128-139): ONE env runs its outermost reset; frame84 u8 [84*84]
+void oracle_atari_chain_reset_index(void* h, int64_t index, uint8_t* frame84) {
+    auto* v = (oracle_atari::VecChain*)h;
+    auto f = v->envs[(size_t)index].top->reset();
+    std::memcpy(frame84, f.data(), 7056);
+}
 // SyncVecEnv::stepWait with auto-reset (sync_env.h:89-105)
 void oracle_atari_chain_step(void* h, const int32_t* actions, uint8_t* frames84, float* reward, uint8_t* done, uint8_t* has_ep, float* ep_r, float* ep_l,
                              int32_t* lives) {

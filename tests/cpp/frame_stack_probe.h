@@ -3,8 +3,10 @@
 // (std::unique_ptr<gym::VecEnv<false>>); every returned observation is dumped for tests/test_cpp_host.py to compare with the
 // oracle's frame stack.  Compiled (a) against the stand-alone mirror (tests/cpp/hip_vec_frame_stack_demo.cpp) and (b) against
 // the REFERENCE's own base.h / vec_env_wrapper.h / spaces (oracle/ref_driver/ref_dropin_tu.cpp, mode "framestack").
-// args: <mode: plain|as_written|norm|norm_as_written|clear> <n_envs> <H> <W> <n_stack> <steps> <host|device> <out.bin>
+// args: <mode: plain|as_written|norm|norm_as_written|clear|reset_index_as_written> <n_envs> <H> <W> <n_stack> <steps> <host|device> <out.bin>
 // out.bin: (steps + 1) observations back to back (row 0 = reset) in the mode's dtype, then per step: reward[N] f32, done[N] f32.
+// out.bin.ri: the reset(int index) leg — what reset(1) returned (env 1's stacked observation; the whole batch in the as-written
+// form), then the whole batch after one more step.
 #pragma once
 #include <cstdio>
 #include <cstdlib>
@@ -20,14 +22,16 @@ struct ScriptedImageVecEnv : gym::VecEnv<false> {
     ScriptedImageVecEnv(int n, int H, int W, bool on_device)
         : gym::VecEnv<false>(n, std::make_shared<gym::Box<uint8_t>>(gym::Range<uint8_t>{0, 255}, gym::Shape{{(int64_t)H, (int64_t)W, 1}, c10::kChar}),
                              std::make_shared<gym::Discrete>(2)), H(H), W(W), on_device(on_device) {}
-    torch::Tensor frame() const {
-        auto x = torch::empty({(int64_t)numEnvs, (int64_t)H, (int64_t)W, 1}, torch::kUInt8);
+    torch::Tensor frame(int64_t first = 0, int64_t count = -1, int64_t at = -1) const {
+        if (count < 0) count = numEnvs;
+        if (at < 0) at = t;
+        auto x = torch::empty({count, (int64_t)H, (int64_t)W, 1}, torch::kUInt8);
         uint8_t* p = x.data_ptr<uint8_t>();
-        for (int64_t e = 0; e < numEnvs; e++)
+        for (int64_t e = first; e < first + count; e++)
             for (int64_t q = 0; q < (int64_t)H * W; q++) {
-                uint32_t v = (uint32_t)(e * 2654435761u) ^ (uint32_t)(t * 40503u) ^ (uint32_t)(q * 2246822519u);
+                uint32_t v = (uint32_t)(e * 2654435761u) ^ (uint32_t)(at * 40503u) ^ (uint32_t)(q * 2246822519u);
                 v ^= v >> 15; v *= 2246822519u; v ^= v >> 13;
-                p[e * H * W + q] = (uint8_t)(v >> 8);
+                p[(e - first) * H * W + q] = (uint8_t)(v >> 8);
             }
         return on_device ? x.to(torch::kCUDA) : x;
     }
@@ -39,7 +43,7 @@ struct ScriptedImageVecEnv : gym::VecEnv<false> {
         for (int64_t e = 0; e < numEnvs; e++) { reward[e][0] = float(t + e); done[e][0] = ((t + e) % 5 == 0) ? 1.f : 0.f; }
         return {frame(), reward, done, std::vector<gym::AnyMap>(numEnvs)};
     }
-    torch::Tensor reset(int) override { return {}; }
+    torch::Tensor reset(int index) override { return frame(index, 1, 1000 + index)[0]; }   // SyncVecEnv::reset(int): ONE env's [H, W, 1] observation (sync_env.h:128-139)
     StepT step(int, torch::Tensor const&) noexcept override { return {}; }
     void render() const override {}
 };
@@ -51,6 +55,7 @@ inline int run(char** a) {   // a[0..7] = the eight arguments above
     gym::HipVecFrameStackOptions o;
     o.asWritten = mode == "as_written" || mode == "norm_as_written";
     o.clearOnDone = mode == "clear";
+    o.resetIndexAsWritten = mode == "reset_index_as_written";
     auto inner = std::make_unique<ScriptedImageVecEnv>(n, H, W, on_device);
     std::unique_ptr<gym::VecEnv<false>> env;
     try {
@@ -73,7 +78,20 @@ inline int run(char** a) {   // a[0..7] = the eight arguments above
     }
     for (auto& t : rd) dump(t);
     std::fclose(f);
-    try { env->reset(0); std::printf("reset_index accepted\n"); } catch (std::exception const& e) { std::printf("reset_index throws\n"); }
+    // reset(int index): env 1 alone starts over (or, as written, one frame is broadcast over every stack), then the batch steps on
+    if (n > 1) {
+        FILE* g = std::fopen((std::string(a[7]) + ".ri").c_str(), "wb"); if (!g) return 2;
+        auto dump2 = [&](torch::Tensor const& x) { auto c = x.to(torch::kCPU).contiguous(); std::fwrite(c.data_ptr(), c.element_size(), c.numel(), g); };
+        try {
+            auto ri = env->reset(1);
+            std::printf("reset_index dims"); for (auto d : ri.sizes()) std::printf(" %lld", (long long)d); std::printf("\n");
+            dump2(ri);
+            auto r = env->step(torch::zeros({n}, torch::kInt64));
+            if (!r.observation.defined()) return 5;
+            dump2(r.observation);
+        } catch (std::exception const& e) { std::printf("reset_index throws %s\n", e.what()); }
+        std::fclose(g);
+    }
     return 0;
 }
 

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "fake_emulator.h"
 #include "gym/hip_atari_vec_env.h"
@@ -62,6 +63,21 @@ int main(int argc, char** argv) {
     auto all = (r.observation * 255.f).round().to(torch::kUInt8).to(torch::kCPU).contiguous();
     put(f, all.data_ptr<uint8_t>(), (size_t)n * 4 * P);
     std::fclose(f);
+    // reset(int index) (sync_env.h:128-139 under the stack): env 1 alone re-runs its reset chain; its stack starts over, the other
+    // envs keep theirs; then the batch steps on.  <out>.ri = env 1's returned observation [4][84][84] as bytes, then the whole batch.
+    {
+        FILE* g = std::fopen((std::string(argv[6]) + ".ri").c_str(), "wb");
+        if (!g) return 5;
+        auto ri = env->reset(1);
+        if (!ri.defined() || ri.sizes() != torch::IntArrayRef({4, 84, 84})) return 10;
+        auto b1 = (ri * 255.f).round().to(torch::kUInt8).to(torch::kCPU).contiguous();
+        if (fwrite(b1.data_ptr<uint8_t>(), 1, (size_t)4 * P, g) != (size_t)4 * P) return 9;
+        auto r2 = env->step((idx * 5 + 1) % 6);
+        if (!r2.observation.defined()) return 7;
+        auto b2 = (r2.observation * 255.f).round().to(torch::kUInt8).to(torch::kCPU).contiguous();
+        if (fwrite(b2.data_ptr<uint8_t>(), 1, (size_t)n * 4 * P, g) != (size_t)n * 4 * P) return 9;
+        std::fclose(g);
+    }
     std::printf("ok\n");
     return 0;
 }

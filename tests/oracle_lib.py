@@ -49,6 +49,7 @@ class Oracle:
         l.oracle_atari_chain_create.argtypes = [_i64, _u64, _u64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
         l.oracle_atari_chain_destroy.argtypes = [_vp]
         l.oracle_atari_chain_reset.argtypes = [_vp, _vp]
+        l.oracle_atari_chain_reset_index.argtypes = [_vp, _i64, _vp]
         l.oracle_atari_chain_step.argtypes = [_vp] * 9
         l.oracle_vec_obs_dim.argtypes = [_vp]
         l.oracle_vec_seed.argtypes = [_vp, _u64]
@@ -324,6 +325,12 @@ class AtariChain:
     def reset(self):
         fr = np.empty((self.n, 84, 84), np.uint8)
         self.lib.oracle_atari_chain_reset(self.h, _p(fr))
+        return fr
+
+    def reset_index(self, index):
+        """SyncVecEnv::reset(int index): env `index` alone runs its outermost reset; returns its 84x84 frame."""
+        fr = np.empty((84, 84), np.uint8)
+        self.lib.oracle_atari_chain_reset_index(self.h, int(index), _p(fr))
         return fr
 
     def step(self, actions):

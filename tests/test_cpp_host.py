@@ -161,6 +161,17 @@ def test_atari_front_end_matches_the_reference_chain(oracle, tmp_path, life_loss
     assert np.array_equal(final, stack.transpose(0, 3, 1, 2))                       # VecNormAndPermute view of the VecFrameStack
     assert pos == raw.size
     assert eps >= 2 and dones >= eps and (life_dones > 0) == life_loss              # the script exercised the branches
+    if exe == VE_BIN:
+        # reset(int index): env 1 alone re-runs its outermost reset (sync_env.h:128-139); its stack starts over — zeros + the fresh
+        # frame — the other envs keep theirs, and the next step shifts everybody
+        ri = np.fromfile(str(out) + ".ri", np.uint8)
+        f1 = chain.reset_index(1)
+        stack[1] = 0
+        stack[1, :, :, -1] = f1
+        assert np.array_equal(ri[:4 * 7056].reshape(4, 84, 84), stack[1].transpose(2, 0, 1))
+        o = chain.step((np.arange(n) * 5 + 1) % 6)
+        oracle.framestack_update(stack, o["frame"])
+        assert np.array_equal(ri[4 * 7056:].reshape(n, 4, 84, 84), stack.transpose(0, 3, 1, 2))
 
 
 @pytest.mark.gpu
@@ -271,7 +282,8 @@ REF_DROPIN = os.path.join(ROOT, "oracle", "_ref", "ref_dropin_tu")
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("templates", ["mirror", "reference"])
-@pytest.mark.parametrize("mode,where", [("plain", "host"), ("plain", "device"), ("as_written", "host"), ("norm", "device"), ("norm_as_written", "host"), ("clear", "host")])
+@pytest.mark.parametrize("mode,where", [("plain", "host"), ("plain", "device"), ("as_written", "host"), ("norm", "device"), ("norm_as_written", "host"), ("clear", "host"),
+                                        ("reset_index_as_written", "host")])
 def test_hip_vec_frame_stack_cpp_wraps_any_vec_env(oracle, tmp_path, mode, where, templates):
     """gym::HipVecFrameStack : VecEnvWrapper<false> (gym/hip_vec_frame_stack.h) held as unique_ptr<VecEnv<false>> over a scripted
     VecEnv<false> of {H, W, 1} byte images: the reference's VecFrameStack, and VecNormAndPermute(VecFrameStack(.)), as wrappers of
@@ -290,10 +302,12 @@ def test_hip_vec_frame_stack_cpp_wraps_any_vec_env(oracle, tmp_path, mode, where
     r = subprocess.run(cmd + [mode, str(n), str(H), str(W), str(k), str(steps), where, str(out)], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     lines = r.stdout.strip().splitlines()
-    norm, aw = mode.startswith("norm"), mode.endswith("as_written")
+    norm, aw = mode.startswith("norm"), mode in ("as_written", "norm_as_written")
     assert lines[0] == (f"space {k} {H} {W} type 6 nEnvs {n}" if norm else f"space {H} {W} {k} type 1 nEnvs {n}")      # c10::kFloat = 6, kChar = 1
     assert lines[1] == (f"obs dtype Float dims {n} {k} {H} {W} cuda 1" if norm else f"obs dtype {'Char' if aw else 'Byte'} dims {n} {H} {W} {k} cuda 1")
-    assert lines[2] == "reset_index throws"
+    bcast = mode == "reset_index_as_written"
+    ri_dims = f"{n} {H} {W} {k}" if bcast else (f"{k} {H} {W}" if norm else f"{H} {W} {k}")
+    assert lines[2] == f"reset_index dims {ri_dims}"
     raw = np.fromfile(out, np.uint8)
     per = n * H * W * k * (4 if norm else 1)
     obs = raw[:per * (steps + 1)].reshape(steps + 1, per)
@@ -314,3 +328,25 @@ def test_hip_vec_frame_stack_cpp_wraps_any_vec_env(oracle, tmp_path, mode, where
             assert np.array_equal(obs[t].view(np.float32).reshape(n, k, H, W), want), t
         else:
             assert np.array_equal(obs[t].reshape(n, H, W, k), stack), t
+    if aw:
+        return   # the reset(int index) leg is checked on the intended view (the as-written VIEW has its own first-channel bookkeeping)
+    # reset(int index) (sync_env.h:128-139 under vec_frame_stack.cpp:34-37): env 1 alone starts over — zeros + its fresh frame, the
+    # others untouched — or, as the reference's code has it, every stack shifts and the ONE frame is broadcast over the batch
+    ri = np.fromfile(str(out) + ".ri", np.uint8)
+    fresh = _scripted_image(2, H, W, 1001)[1]                                   # the inner env's reset(1): env 1's frame at its own clock
+    if bcast:
+        oracle.framestack_update(stack, np.ascontiguousarray(np.broadcast_to(fresh, (n, H, W))))
+        first, rest = ri[:per].reshape(n, H, W, k), ri[per:]
+        assert np.array_equal(first, stack)
+    else:
+        stack[1] = 0
+        stack[1, :, :, -1] = fresh
+        one = per // n
+        first, rest = ri[:one], ri[one:]
+        want1 = oracle.norm_permute(stack)[1] if norm else stack[1]
+        assert np.array_equal(first.view(np.float32).reshape(k, H, W) if norm else first.reshape(H, W, k), want1)
+    oracle.framestack_update(stack, _scripted_image(n, H, W, steps + 1))
+    if mode == "clear":
+        stack[np.array([(steps + 1 + e) % 5 == 0 for e in range(n)]), :, :, :-1] = 0
+    want = oracle.norm_permute(stack) if norm else stack
+    assert np.array_equal(rest.view(np.float32).reshape(n, k, H, W) if norm else rest.reshape(n, H, W, k), want)

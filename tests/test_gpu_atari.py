@@ -438,3 +438,28 @@ def test_hip_vec_frame_stack_wraps_any_image_vec_env(oracle, device, norm, view)
         env.reset(0)
     with pytest.raises(RuntimeError):
         HipVecFrameStack(_ImageVecEnv(n, H, W, device), k, channelOrder="first")
+
+
+@pytest.mark.parametrize("view", ["intended", "as_written"])
+@pytest.mark.parametrize("offset", [1, 2, 3, 4, 8])
+def test_nhwc_view_into_a_misaligned_byte_buffer(view, offset):
+    """The channels-last view written at an arbitrary BYTE offset (a slice of a larger uint8 tensor): offsets that are not a multiple
+    of 4 must take the byte path (the packed 32-bit stores would be misaligned), 4 / 8 the dword path; all equal the aligned result."""
+    from gym_amd.atari import AtariPreprocessor
+    n = 37
+    pp = AtariPreprocessor(n, device=0)
+    g = torch.Generator(device="cuda").manual_seed(offset)
+    pp.reset(torch.randint(0, 256, (n, 2, 210, 160, 3), dtype=torch.uint8, device="cuda", generator=g))
+    for _ in range(3):
+        pp.step(torch.randint(0, 256, (n, 2, 210, 160, 3), dtype=torch.uint8, device="cuda", generator=g))
+    pp.set_stack_view(view)
+    want = pp.stacked_nhwc().view(torch.uint8)
+    numel = want.numel()
+    big = torch.full((numel + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+    base = (-big.data_ptr()) % 16                    # make the buffer start 16-B aligned, then add the offset under test
+    out = big[base + offset: base + offset + numel]
+    assert out.data_ptr() % 16 == offset
+    pp.stacked_nhwc(out.view(want.shape) if view == "intended" else out.view(torch.int8).view(want.shape))
+    torch.cuda.synchronize()
+    assert torch.equal(out, want.reshape(-1))
+    assert (big[:base + offset] == 0xAB).all() and (big[base + offset + numel:] == 0xAB).all()   # nothing written outside
