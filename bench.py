@@ -41,6 +41,21 @@ BYTES_PER_STEP = {
 }
 
 
+_BARRIER_TOKEN = {}
+
+
+def rank_barrier(torch, dist):
+    """A barrier over all ranks: an all-reduce of one pre-allocated element + a synchronize.  dist.barrier() does the same job but
+    costs ~2 ms per call on the nccl backend (measured with a 1-rank RCCL group: it allocates, and synchronises the whole device
+    twice), which is most of a 20-step timed region at 0.2 ms per step; this form costs the collective's own latency."""
+    key = dist.get_backend()
+    if key not in _BARRIER_TOKEN:
+        _BARRIER_TOKEN[key] = torch.zeros(1, dtype=torch.float32, device="cuda" if key == "nccl" else "cpu")
+    dist.all_reduce(_BARRIER_TOKEN[key])
+    if key == "nccl":
+        torch.cuda.synchronize()
+
+
 def max_over_ranks(torch, dist, dt):
     """MAX of a host scalar over ranks (device tensor for nccl, host tensor otherwise)."""
     t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -76,12 +91,21 @@ def prewarm(torch, eng, actions, max_steps=None, seconds=PREWARM_SECONDS):
 
 def time_engine(torch, dist, eng, actions, steps, warmup, world, prewarm_max_steps=None):
     """Pre-warm, W untimed + K timed VecEnv steps.  Returns (wall seconds max over ranks, mean kernel ms from HIP events)."""
-    prewarm(torch, eng, actions, prewarm_max_steps)
+    prewarm(torch, eng, actions, None if prewarm_max_steps is None else prewarm_max_steps // 2)   # the other half of a finite tape's allowance is for the re-warm below
     for w in range(warmup):
         eng.step(actions[w % len(actions)])
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        # Two barriers.  The first absorbs the skew between the ranks (and, the first time, the collective library's lazy set-up): the
+        # GPU idles while it waits, and on MI355X the ~25 ms after such a gap run up to 20 % slow (measured with a 1-rank RCCL group:
+        # 0.25 ms per step decaying back to 0.21 over ~100 steps).  So the engine is re-warmed AFTER it, untimed; the ranks then
+        # reach the second barrier together, nobody idles, and the timed region starts on a warm chip.
+        rank_barrier(torch, dist)
+        rewarm = 160 if prewarm_max_steps is None else max(0, min(160, prewarm_max_steps // 2))
+        for w in range(rewarm):
+            eng.step(actions[w % len(actions)])
+        torch.cuda.synchronize()
+        rank_barrier(torch, dist)
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
@@ -90,13 +114,16 @@ def time_engine(torch, dist, eng, actions, steps, warmup, world, prewarm_max_ste
         eng.step(actions[k % len(actions)])
         ev[k][1].record()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        rank_barrier(torch, dist)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         dt = max_over_ranks(torch, dist, dt)
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    if os.environ.get("GYM_BENCH_DUMP_STEPS"):   # debugging aid: every step's own duration and the gaps between them
+        print("per-step ms: " + " ".join(f"{a.elapsed_time(b):.3f}" for a, b in ev), file=sys.stderr, flush=True)
+        print("gaps ms: " + " ".join(f"{ev[k][1].elapsed_time(ev[k + 1][0]):.3f}" for k in range(steps - 1)), file=sys.stderr, flush=True)
     return dt, kern_ms
 
 
@@ -339,8 +366,18 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running as rank {rank} of {world} (the launcher's world wins)", file=sys.stderr, flush=True)
     backend = "none"
-    if world > 1:
+    # GYM_BENCH_FORCE_DIST=1: a 1-GPU rehearsal of the multi-rank code path — the process group is created even for ONE rank, so the
+    # barriers, the max-over-ranks reduction, dist.all_reduce on the engine's device `moments` view over RCCL, the exchange
+    # verification and the collective timing all run exactly as they will on N GPUs
+    dist_on = world > 1 or os.environ.get("GYM_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # Rehearsal knobs for a 1-GPU box only (the real N>1 run is one rank per GPU over RCCL): all ranks on device 0, gloo.
         if os.environ.get("GYM_BENCH_SINGLE_DEVICE") == "1":
@@ -356,7 +393,7 @@ def main():
         local_rank = 0
     n = args.envs_per_gpu
     failures = []   # self-checks that did not hold (N > 1 exchange verification): the line still comes out, the exit code is 6
-    ranks_seen = dist.get_world_size() if world > 1 else 1
+    ranks_seen = dist.get_world_size() if dist_on else 1
     if ranks_seen != world:
         raise RuntimeError(f"torch.distributed reports {ranks_seen} ranks, the environment says {world}")
     PREWARM_TAPE_STEPS = 64   # engine steps a finite reset tape is sized for beyond W + K (the rest of the pre-warm is a copy loop)
@@ -432,11 +469,11 @@ def main():
         w = (L.WRAP_TIME_LIMIT | L.WRAP_CLIP_REWARD | L.WRAP_MONITOR | L.WRAP_NORM_OBS | L.WRAP_NORM_REWARD | L.WRAP_NORM_TRAINING)
         eng = Engine(EngineConfig(env_kind=L.ENV_MOUNTAINCAR, n_envs=n3, precision=L.PRECISION_LOCKSTEP_F64, reset_mode=L.RESET_COUNTER_RNG,
                                   wrappers=w, max_episode_steps=200, env_offset=rank * n3), local_rank)
-        if world > 1 and form == "rows":
+        if dist_on and form == "rows":
             eng.set_exchange_form(L.EXCHANGE_ROWS)   # no reduce launch: the partial rows themselves are all-reduced (gymhip.h)
 
         def do_reset():
-            if world > 1:
+            if dist_on:
                 eng.reset_begin()
                 allreduce_sum(eng.moments)
                 eng.reset_finish()
@@ -444,7 +481,7 @@ def main():
                 eng.reset()
 
         def do_step(a):
-            if world > 1:
+            if dist_on:
                 eng.step_begin(a)
                 allreduce_sum(eng.moments)
                 eng.step_finish()
@@ -457,21 +494,25 @@ def main():
         for k in range(50 if n3 <= (1 << 21) else 10):
             do_step(acts[k % 4])
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if dist_on:   # barrier, untimed re-warm, barrier: as in time_engine (the idle wait at the first one costs the next ~25 ms their clocks)
+            rank_barrier(torch, dist)
+            for k in range(200 if n3 <= (1 << 21) else 40):
+                do_step(acts[k % 4])
+            torch.cuda.synchronize()
+            rank_barrier(torch, dist)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(steps):
             do_step(acts[k % 4])
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if dist_on:
+            rank_barrier(torch, dist)
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             dt = max_over_ranks(torch, dist, dt)
         stats = eng.get_norm_stats()
         out = {}
-        if world > 1:
+        if dist_on:
             # Self-check of the exchange (no multi-rank RCCL run exists before the 8-GPU box sees this): the all-reduced batch count must be
             # the sum of the ranks' env counts and the replicated statistics bit-identical on every rank.  A failure fails the run.
             ok, why = verify_replicated(torch, dist, float(eng.moments[0 if form == "moments" else 15].item()), n3, stats)
@@ -483,7 +524,7 @@ def main():
             for _ in range(20):
                 allreduce_sum(payload)
             torch.cuda.synchronize()
-            dist.barrier()
+            rank_barrier(torch, dist)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 200
@@ -499,7 +540,7 @@ def main():
         bps = 16 + 16 + 4 + 8 + 8 + 4 + 4 + (8 + 8 + 4 + 4)   # step kernel 60 B + normalise kernel 24 B
         out.update({"value": world * n3 * steps / dt, "unit": "env-steps/s", "envs_per_gpu": n3, "ms_per_step": round(dt / steps * 1e3, 4),
                     "bytes_per_env_step": bps, "achieved_GBs": round(bps * n3 * steps / dt / 1e9, 1), "frac": round(bps * n3 * steps / dt / 1e9 / HBM_PEAK_GBS, 4),
-                    "collective": f"all_reduce({eng.moments_len} x f64)/step, backend {backend}, exchange form {form}" if world > 1 else None, "obs_count": float(stats[4])})
+                    "collective": f"all_reduce({eng.moments_len} x f64)/step, backend {backend}, exchange form {form}" if dist_on else None, "obs_count": float(stats[4])})
         return out
 
     def measure_config2():
@@ -706,7 +747,7 @@ def main():
             "config": {"workload": f"{args.env} vec_env, {n} envs/GPU, TimeLimit+Monitor, fused step+auto-reset ({'in-kernel counter-RNG' if args.reset_mode == 'rng' else 'reset-tape'} resets), {args.mode} arithmetic, "
                                    f"one kernel launch per VecEnv::step (BASELINE configs[4])",
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": f"env-shard x{world}, no data-path collective",
-                       "ranks_seen": ranks_seen, "backend": backend, "launched_by": "bench.py" if os.environ.get("GYM_BENCH_SELF_LAUNCHED") else ("torchrun/env" if world > 1 else "single process"),
+                       "ranks_seen": ranks_seen, "backend": backend, "launched_by": "bench.py" if os.environ.get("GYM_BENCH_SELF_LAUNCHED") else ("torchrun/env" if world > 1 else ("single process, forced 1-rank process group" if dist_on else "single process")),
                        "error_flag": main_m["error_flag"], "episodes_finished_rank0": main_m["episodes"]},
             "roofline": {"bound": "hbm", "achieved": round(main_m["achieved_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(main_m["achieved_gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -773,7 +814,7 @@ def main():
         guarded("config2_cartpole_lockstep_65536", measure_config2)
         guarded("cartpole_lockstep_rollout_32_steps_per_launch", measure_rollout_big)
         guarded("config3_mountaincar_vecnormalize_131072_per_gpu", measure_config3, 1 << 17, max(args.steps, 500))   # configs[2]'s per-GPU shard on 8 GPUs
-        if world > 1:   # the exchange form without the reduce launch (32 KB payload): measured next to the default on every multi-rank run
+        if dist_on:   # the exchange form without the reduce launch (32 KB payload): measured next to the default on every multi-rank run
             guarded("config3_mountaincar_vecnormalize_131072_per_gpu_rows_exchange", measure_config3, 1 << 17, max(args.steps, 500), "rows")
         guarded("config3_mountaincar_vecnormalize_1M_per_gpu", measure_config3, 1 << 20, max(args.steps, 200))
         guarded("config3_mountaincar_vecnormalize_16M_per_gpu", measure_config3, 1 << 24, max(20, args.steps // 4))
@@ -801,7 +842,7 @@ def main():
     if failures:
         extra["error"] = "; ".join(failures)
     emit()
-    if world > 1:
+    if dist_on:
         try:
             dist.barrier()
             dist.destroy_process_group()
