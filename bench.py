@@ -720,7 +720,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            rec = json.load(open(tpath)).get(f"{args.env}_{args.mode}" + ("_tape" if args.reset_mode == "tape" and args.env == "cartpole" else ""), {})
+            rec = json.load(open(tpath)).get(f"{args.env}_{args.mode}" + ({"tape": "_tape", "mt19937": "_mt19937"}.get(args.reset_mode, "") if args.env == "cartpole" else ""), {})
             if rec.get("envs_per_launch") == n:
                 traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
@@ -744,7 +744,7 @@ def main():
             "timed_region_s": round(main_m["timed_region_s"], 6), "prewarm_s": PREWARM_SECONDS,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.mode == "lockstep" else "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.env} vec_env, {n} envs/GPU, TimeLimit+Monitor, fused step+auto-reset ({'in-kernel counter-RNG' if args.reset_mode == 'rng' else 'reset-tape'} resets), {args.mode} arithmetic, "
+            "config": {"workload": f"{args.env} vec_env, {n} envs/GPU, TimeLimit+Monitor, fused step+auto-reset ({ {'rng': 'in-kernel counter-RNG', 'tape': 'reset-tape', 'mt19937': 'per-env device-resident std::mt19937'}[args.reset_mode] } resets), {args.mode} arithmetic, "
                                    f"one kernel launch per VecEnv::step (BASELINE configs[4])",
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": f"env-shard x{world}, no data-path collective",
                        "ranks_seen": ranks_seen, "backend": backend, "launched_by": "bench.py" if os.environ.get("GYM_BENCH_SELF_LAUNCHED") else ("torchrun/env" if world > 1 else ("single process, forced 1-rank process group" if dist_on else "single process")),
