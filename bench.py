@@ -596,7 +596,7 @@ def main():
         return {"value": n * K / (ms * 1e-3), "unit": "env-steps/s (per GPU)", "envs": n, "steps_per_launch": K, "us_per_step": round(ms / K * 1e3, 2), "error_flag": err}
 
     def measure_pcie_inclusive(steps):
-        """What the rates become if a caller keeps actions / results / frames on the HOST (never `value`; DESIGN.md §5):
+        """What the rates become if a caller keeps actions / results / frames on the HOST (never `value`; DESIGN.md §6):
         (a) the headline CartPole step with int32 actions from pinned host memory and obs/reward/done copied back to it;
         (b) the Atari step with palette-index screens uploaded from pinned host memory every step."""
         out = {}

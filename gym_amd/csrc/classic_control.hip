@@ -8,7 +8,7 @@
 //
 // Build with -ffp-contract=off: the lockstep path must round exactly where a stock x86-64 g++ build of the reference
 // rounds (no FMA).  HBM-bound integer/float streaming work: no MFMA, no LDS tiling — coalescing and enough bytes in
-// flight are what matter (DESIGN.md §3).
+// flight are what matter (DESIGN.md §4).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -408,7 +408,7 @@ template <> struct EnvTraits<KIND_MOUNTAINCAR> { static constexpr int F = 2; sta
 // State I/O.  F32: the f32 obs rows [N][F] ARE the state (float4 / float2 per lane).  LOCKSTEP: the same obs rows plus
 // int32 residual rows [N][F] that complete each float to the exact double (split-double, below).
 // ------------------------------------------------------------------------------------------------------------
-// Compile-time tuning knobs (profiles/ and DESIGN.md §5 record what each is worth on MI355X):
+// Compile-time tuning knobs (profiles/NOTES.md records what each is worth on MI355X):
 //   GYMHIP_NT   1 = non-temporal loads/stores on the once-per-step streams (working set >> 256 MiB Infinity Cache)
 #ifndef GYMHIP_NT
 #define GYMHIP_NT 1

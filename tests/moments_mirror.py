@@ -1,4 +1,4 @@
-"""Test infrastructure: host mirror of the normaliser's all-reduce payload (DESIGN.md §6) — numpy, float64/float32 exactly as the kernels.  Not part of the product package: it lets the sharded reduction be checked on CPU with gloo.
+"""Test infrastructure: host mirror of the normaliser's all-reduce payload (DESIGN.md §5) — numpy, float64/float32 exactly as the kernels.  Not part of the product package: it lets the sharded reduction be checked on CPU with gloo.
 
 The step kernel emits, per GPU, shifted power sums of the observations and discounted returns plus episode counters:
 

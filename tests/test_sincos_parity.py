@@ -4,7 +4,7 @@ argument reduction).  Both are < 1 ulp in double, so the floats can differ only 
 ulp of a float rounding tie.  This file QUANTIFIES that:
 
   * CPU: the kernel polynomial's host twin vs glibc over a dense sweep of the whole reachable angle range — mismatches counted
-    (measured once over 1.6e10 angles x 2 functions: 0) — and over frozen adversarial near-tie angles, where
+    (measured once over 1.6e10 angles x 2 functions: 0; profiles/NOTES.md, former DESIGN §7) — and over frozen adversarial near-tie angles, where
     mismatches DO occur and their number is pinned;
   * GPU: the device function equals the host twin bit for bit in double, so the CPU counts are the device's counts.
 """
