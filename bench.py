@@ -572,8 +572,29 @@ def main():
         roll = (time.perf_counter() - t0) / (2 * K)
         err = eng.poll_error()
         eng.close()
+        # the same size with the reference's own reset streams resident on the device (GYMHIP_RESET_MT19937): 12,000 steps, i.e. every env's
+        # generator block is regenerated >= 3 times inside the timed region (one regeneration per 156 episodes of an env)
+        mt = Engine(EngineConfig(env_kind=L.ENV_CARTPOLE, n_envs=n2, precision=L.PRECISION_LOCKSTEP_F64, reset_mode=L.RESET_MT19937,
+                                 wrappers=L.WRAP_TIME_LIMIT | L.WRAP_MONITOR, max_episode_steps=500, env_offset=rank * n2), local_rank)
+        mt.seed(0)
+        mt.reset()
+        acts4 = [torch.randint(0, 2, (n2,), dtype=torch.int32, device="cuda", generator=g) for _ in range(4)]
+        for k in range(100):
+            mt.step(acts4[k % 4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(12000):
+            mt.step(acts4[k % 4])
+        torch.cuda.synchronize()
+        mt_step = (time.perf_counter() - t0) / 12000
+        cur = mt.counters()["cursor"]
+        mt_rows, mt_rows_median = int(cur.min()), int(cur.float().median())
+        err |= mt.poll_error()
+        mt.close()
         return {"envs": n2, "step_api": {"value": n2 / per_step, "unit": "env-steps/s (per GPU)", "us_per_step": round(per_step * 1e6, 2)},
                 "rollout_500_steps_per_launch": {"value": n2 / roll, "unit": "env-steps/s (per GPU)", "us_per_step": round(roll * 1e6, 3)},
+                "step_api_device_mt19937_resets": {"value": n2 / mt_step, "unit": "env-steps/s (per GPU)", "us_per_step": round(mt_step * 1e6, 2), "steps": 12000,
+                                                   "regenerations_per_env_median": mt_rows_median // 156, "regenerations_per_env_at_least": mt_rows // 156},
                 "error_flag": err}
 
     def measure_rollout_big(K=32):

@@ -59,6 +59,8 @@ struct HipVecEnvOptions {
     // Sharded runs with the normaliser on: sums `count` doubles at `moments` (device) over all ranks on `stream`
     // (e.g. ncclAllReduce(moments, moments, count, ncclDouble, ncclSum, comm, stream)).  Empty = single GPU.
     std::function<void(double* moments, size_t count, void* stream)> allreduce;
+    bool exchange_rows = false;               // what `allreduce` is handed: false = 2F+6 reduced doubles (GYMHIP_EXCHANGE_MOMENTS), true = the step
+                                              // kernel's partial rows themselves, 32-64 KB, one launch fewer per step (GYMHIP_EXCHANGE_ROWS)
 };
 
 class HipVecEnv : public VecEnv<false>, public Updateable<VecNormalizeStateRewardPair<false>> {
@@ -282,7 +284,8 @@ private:
         } else if (c.reset_mode == GYMHIP_RESET_MT19937 && seeded) {
             if (!ok(gymhip_seed(h, seed_value), "gymhip_seed")) return giveUp();   // never seeded = default-constructed generators, as in the reference
         }
-        if (!ok(gymhip_get_buffers(h, &buf), "gymhip_get_buffers")) return giveUp();
+        if (opt.exchange_rows && hasNorm() && opt.allreduce && !ok(gymhip_set_exchange_form(h, GYMHIP_EXCHANGE_ROWS), "gymhip_set_exchange_form")) return giveUp();
+        if (!ok(gymhip_get_buffers(h, &buf), "gymhip_get_buffers")) return giveUp();   // after the form is set: moments / moments_len follow it
         const int64_t n = opt.n_envs, F = buf.obs_dim;
         obs = view(buf.obs, {n, F}, c10::kFloat);
         obs_norm = view(buf.obs_norm, {n, F}, c10::kFloat);

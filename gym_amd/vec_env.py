@@ -158,9 +158,12 @@ class HipVecEnv(VecEnv):
 
     def __init__(self, env_id: str, n_envs: int, max_episode_steps: int | None = None, clip_reward: bool = False, monitor: bool = True,
                  lockstep: bool = True, reset_mode: str | None = None, tape_episodes: int | None = None, device: int | None = None,
-                 rank: int | None = None, world: int | None = None, process_group=None, auto_reset: bool = True):
+                 rank: int | None = None, world: int | None = None, process_group=None, auto_reset: bool = True, exchange: str = "moments"):
         if env_id not in _ENV_IDS:
             raise ValueError(f"unknown env id {env_id!r}; the engine implements {sorted(_ENV_IDS)}")
+        if exchange not in ("moments", "rows"):
+            raise ValueError("exchange must be 'moments' (reduce launch + 2F+6 doubles) or 'rows' (the partial rows themselves, no reduce launch)")
+        self._exchange = exchange   # sharded runs with the normaliser on: what the ranks all-reduce per step (gymhip_set_exchange_form)
         self._auto_reset = bool(auto_reset)   # SyncVecEnv(envs, auto_reset) (sync_env.h:28,44): off = finished envs wait for reset(index)
         self.kind = _ENV_IDS[env_id]
         self.rank = int(os.environ.get("RANK", 0)) if rank is None else rank
@@ -215,6 +218,8 @@ class HipVecEnv(VecEnv):
                            reset_mode=self._reset_mode, wrappers=w, max_episode_steps=self._max_steps, env_offset=self.env_offset,
                            seed=self._seed if self._seed is not None else 0, **kw)
         self.engine = Engine(cfg, self._device)
+        if self._exchange == "rows" and self._has_norm() and self.world > 1:
+            self.engine.set_exchange_form(L.EXCHANGE_ROWS)
         if self._reset_mode == L.RESET_TAPE:
             if self._seed is None:
                 # every unseeded reference env draws from the same default stream: one row set, replicated

@@ -31,7 +31,7 @@ def _worker(rank, world, port, n, T, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tests import moments_mirror as M
-    from gym_amd.vec_env import shard_range
+    from gym_amd.vec_env import allreduce_sum, shard_range   # the PRODUCT's partitioning rule and all-reduce call (its non-nccl path)
     from tests.oracle_lib import MOUNTAINCAR, F_CLIP_REWARD, F_MONITOR, F_TIME_LIMIT, Oracle, splitmix_actions
     o = Oracle()
     lo, hi = shard_range(n, rank, world)
@@ -42,7 +42,7 @@ def _worker(rank, world, port, n, T, out_dir):
 
     def allreduce(m):
         t = torch.from_numpy(m)
-        dist.all_reduce(t)            # the call HipVecEnv._allreduce_moments makes on the device payload
+        allreduce_sum(t)              # gym_amd.vec_env.allreduce_sum: what HipVecEnv._allreduce_moments calls on the payload
         return t.numpy()
 
     obs = shard.reset()

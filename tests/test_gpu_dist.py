@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, T, out_dir):
+def _worker(rank, world, port, n, T, out_dir, exchange="moments"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
@@ -32,7 +32,7 @@ def _worker(rank, world, port, n, T, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gym_amd.vec_env import HipVecEnv, TrainingVecNormRO, shard_range
     from tests.oracle_lib import splitmix_actions
-    env = TrainingVecNormRO(HipVecEnv("MountainCar-v0", n, max_episode_steps=200, clip_reward=True, monitor=True, device=0, rank=rank, world=world))
+    env = TrainingVecNormRO(HipVecEnv("MountainCar-v0", n, max_episode_steps=200, clip_reward=True, monitor=True, device=0, rank=rank, world=world, exchange=exchange))
     lo, hi = shard_range(n, rank, world)
     assert env.nEnvs() == hi - lo
     obs = env.reset()
@@ -50,11 +50,12 @@ def _worker(rank, world, port, n, T, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_sharded_vecnormalize_matches_single_process_oracle(tmp_path, oracle):
+@pytest.mark.parametrize("exchange", ["moments", "rows"])
+def test_two_rank_sharded_vecnormalize_matches_single_process_oracle(tmp_path, oracle, exchange):
     from gym_amd.vec_env import shard_range
     from tests.oracle_lib import MOUNTAINCAR, F_CLIP_REWARD, F_MONITOR, F_TIME_LIMIT, splitmix_actions
     n, T, world = 6000, 230, 2
-    mp.spawn(_worker, args=(world, _free_port(), n, T, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, T, str(tmp_path), exchange), nprocs=world, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
     assert np.array_equal(r[0]["stats"], r[1]["stats"])                            # replicated statistics never drift apart
     assert np.array_equal(r[0]["episodes"], r[1]["episodes"])
