@@ -419,7 +419,7 @@ def main():
         acts = [torch.randint(0, n_act, (n,), dtype=torch.int32, device="cuda", generator=g) for _ in range(4)]
         return eng, acts
 
-    def measure(env, mode, reset_mode=None, steps=None):
+    def measure(env, mode, reset_mode=None, steps=None, inspect=None):
         eng, acts = build(env, mode, reset_mode)
         tape_mode = env == "cartpole" and (reset_mode or args.reset_mode) == "tape"
         steps = steps or args.steps
@@ -427,6 +427,7 @@ def main():
         err = eng.poll_error()
         eps = eng.episode_stats()
         li = eng.launch_info()
+        seen = inspect(eng) if inspect else None
         eng.close()
         del eng, acts
         torch.cuda.empty_cache()
@@ -438,7 +439,7 @@ def main():
         return {
             "value": world * n * steps / dt, "ms_per_step": dt / steps * 1e3, "kernel_ms": kern_ms, "timed_region_s": dt, "steps": steps,
             "achieved_gbs": achieved, "bytes_per_env_step": bps, "error_flag": err, "episodes": eps[0],
-            "hbm_only_bytes_per_env_step": None if kept is None else bps - 4 * kept, "launch": li,
+            "hbm_only_bytes_per_env_step": None if kept is None else bps - 4 * kept, "launch": li, "inspected": seen,
         }
 
     def measure_cache_swept(steps=40):
@@ -803,24 +804,31 @@ def main():
     dog.daemon = True
     dog.start()
 
+    spent = extra.setdefault("seconds_per_measurement", {})   # wall-clock of each secondary measurement on rank 0 (sizes the watchdog)
+
     def guarded(key, fn, *a):
         in_flight[0] = key
+        t0 = time.perf_counter()
         try:
             extra[key] = fn(*a)
         except Exception as e:  # noqa: BLE001 — report, never lose the headline line
             extra[key] = {"error": f"{type(e).__name__}: {e}"}
+        spent[key] = round(time.perf_counter() - t0, 2)
 
-    def classic(env, mode, reset_mode=None, steps=None):
-        m = measure(env, mode, reset_mode, steps)
-        return {"value": m["value"], "unit": "env-steps/s", "kernel_ms": round(m["kernel_ms"], 4), "steps": m["steps"],
+    def classic(env, mode, reset_mode=None, steps=None, inspect=None):
+        m = measure(env, mode, reset_mode, steps, inspect)
+        return {**(m["inspected"] or {}), "value": m["value"], "unit": "env-steps/s", "kernel_ms": round(m["kernel_ms"], 4), "steps": m["steps"],
                 "bytes_per_env_step": m["bytes_per_env_step"], "achieved_GBs": round(m["achieved_gbs"], 1),
                 "frac": round(m["achieved_gbs"] / HBM_PEAK_GBS, 4), "error_flag": m["error_flag"]}
 
     def mt19937_resets():
         """The reference-exact reset source at scale: per-env std::mt19937 states on the device (GYMHIP_RESET_MT19937).  An env's
-        624-word generator block is regenerated once per 156 of its episodes (~3,500 random-policy steps), so the timed region is long
-        enough to hold a whole period: every env regenerates at least once inside it."""
-        out = classic("cartpole", "lockstep", "mt19937", steps=max(args.steps, 4000))
+        624-word generator block is regenerated once per 156 of its episodes (~3,500 random-policy steps); the timed region is
+        20,000 steps, so that every env regenerates its block at least 3 times inside it (reported from the envs' cursors)."""
+        def regenerations(eng):
+            cur = eng.counters()["cursor"]
+            return {"episodes_per_env_at_least": int(cur.min()), "regenerations_per_env_at_least": int(cur.min()) // 156, "regenerations_per_env_median": int(cur.float().median()) // 156}
+        out = classic("cartpole", "lockstep", "mt19937", steps=max(args.steps, 20000), inspect=regenerations)
         out["note"] = "reset states = std::mt19937(seed + env index) per env, seeded / twisted / tempered on the GPU; bit-identical to a host-drawn tape (tests/test_gpu_mt19937.py)"
         return out
 
