@@ -67,6 +67,54 @@ def test_cartpole_lockstep_16m_envs_shard_equality_conservation_oracle(oracle):
     assert done_total > N_FULL                                                      # on average every env finished an episode
 
 
+def test_cartpole_mt19937_16m_envs_shard_equality_and_oracle_across_a_regeneration(oracle):
+    """The reference-exact reset source at the full size: 16,777,216 device-resident std::mt19937 states (39 GiB), TimeLimit(9) so
+    that every env finishes an episode at least every 9 steps and all of them regenerate their 624-word block inside the run (a
+    regeneration per 156 episodes: the wave-cooperative in-place twist at scale).  Shards of the env range run as their own small
+    engines reproduce the big engine's rows bit for bit, and the oracle — per-env std::mt19937(seed + global index) objects on the
+    CPU — replays each shard: observations, done flags and the fp64 state."""
+    from gym_amd import _lib as L
+    from gym_amd.engine import Engine, EngineConfig
+    T, seed, tl = 1500, 11, 9
+    w = L.WRAP_TIME_LIMIT | L.WRAP_MONITOR
+
+    def mk(n, off):
+        e = Engine(EngineConfig(env_kind=L.ENV_CARTPOLE, n_envs=n, precision=L.PRECISION_LOCKSTEP_F64, reset_mode=L.RESET_MT19937,
+                                wrappers=w, max_episode_steps=tl, env_offset=off), 0)
+        e.seed(seed)
+        e.reset()
+        return e
+
+    big = mk(N_FULL, 0)
+    shards = [(0, 2048), (N_FULL // 2 - 1000, 3000), (N_FULL - 2048, 2048)]          # first, middle (unaligned: partial waves), last
+    small, ovs = [], []
+    for off, n in shards:
+        e = mk(n, off)
+        assert torch.equal(e.obs, big.obs[off:off + n])
+        ov = oracle.vec(CARTPOLE, n, F_TIME_LIMIT | F_MONITOR, tl)
+        ov.seed(seed + off)                                                          # env i of the shard <- mt19937(seed + off + i)
+        assert np.array_equal(ov.reset(), e.obs.cpu().numpy())
+        small.append(e); ovs.append(ov)
+    for t in range(T):
+        big.step(_actions(N_FULL, t, 2))
+        check = t % 100 == 99 or t == T - 1
+        for (off, n), e, ov in zip(shards, small, ovs):
+            a = _actions(n, t, 2, off)
+            e.step(a)
+            r = ov.step(a.cpu().numpy(), want64=check)
+            if check:
+                assert torch.equal(e.obs, big.obs[off:off + n]) and torch.equal(e.done, big.done[off:off + n]) and \
+                    torch.equal(e.counter, big.counter[off:off + n]), (t, off)
+                assert np.array_equal(e.obs.cpu().numpy(), r["obs"]) and np.array_equal(e.done.cpu().numpy(), r["done"]), (t, off)
+                assert np.array_equal(e.state_f64().cpu().numpy(), r["obs64"]), (t, off)
+    cur = big.counters()["cursor"]
+    assert int(cur.min()) > 156, int(cur.min())                                      # every one of the 16.7 M envs regenerated after its first twist
+    for (off, n), e in zip(shards, small):
+        assert torch.equal(e.state_f64(), big.state_f64()[off:off + n]), off
+        assert torch.equal(e.mt_state, big.mt_state[off:off + n]), off               # the generator blocks themselves
+    assert big.poll_error() == 0
+
+
 def test_mountaincar_normalised_16m_envs_determinism_and_float32_count():
     """config 3's stack at config 5's size: two engines agree bit for bit, and `m_Count` follows the reference's float32
     accumulation (the 1e-4 initial count is absorbed by the first 2^24-row batch)."""
