@@ -120,12 +120,32 @@ __device__ inline void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_RE
 // Collective over the ACTIVE lanes of a wave (call it from converged code).  A lane with `want` gets the four raw (tempered)
 // outputs of its env's next reset row in `raw`; `cursor` = rows its env has consumed so far (mod kMtCursorPeriod).
 // `lds` = this wave's private 624-word scratch.
+// Starts reading one env's generator block into the wave's LDS scratch WITHOUT holding registers (LDS-DMA: three 16-B-per-lane
+// global_load_lds, non-temporal), for the first lane with `likely` — the caller's exact forecast, made before the dynamics, that the lane
+// will need a twist at the end of this step — so that the block's HBM round trip runs under the step's arithmetic instead of stalling
+// the wave afterwards.  Full waves only.  Returns that lane (wave-uniform) or -1; mt_draw_row(..., prefetched) consumes it.
+using global_cptr = const __attribute__((address_space(1))) void*;
+using lds_ptr = __attribute__((address_space(3))) void*;
+__device__ inline int mt_prefetch_block(bool likely, const uint32_t* __restrict__ mt_state, int64_t i, uint32_t* lds) {
+    const uint64_t m = __ballot(likely);
+    if (!m || __popcll(__ballot(1)) != 64) return -1;
+    const int src = __builtin_ctzll(m), lane = (int)__lane_id();
+    const int64_t ei = ((int64_t)__shfl((int)(i >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)i, src);
+    const uint32_t* st = mt_state + ei * kMtWords + 4 * lane;            // 2,496 B per env: 16-B aligned
+    __builtin_amdgcn_global_load_lds((global_cptr)st, (lds_ptr)lds, 16, 0, 2);                     // LDS destination = base + lane * 16
+    __builtin_amdgcn_global_load_lds((global_cptr)(st + 256), (lds_ptr)(lds + 256), 16, 0, 2);
+    if (lane < (kMtWords - 512) / 4) __builtin_amdgcn_global_load_lds((global_cptr)(st + 512), (lds_ptr)(lds + 512), 16, 0, 2);
+    return src;
+}
+
 template <bool SAME_LAUNCH_WRITES = false>   // true (rollout kernel): an env's block may have been rewritten earlier in this launch, by other lanes
-__device__ inline void mt_draw_row(bool want, uint32_t cursor, uint32_t* __restrict__ mt_state, int64_t i, uint32_t* lds, uint32_t (&raw)[4]) {
+__device__ inline void mt_draw_row(bool want, uint32_t cursor, uint32_t* __restrict__ mt_state, int64_t i, uint32_t* lds, uint32_t (&raw)[4],
+                                   int prefetched = -1) {   // prefetched: the lane whose block mt_prefetch_block has on its way into `lds`
     const uint32_t pos = cursor % (uint32_t)kMtRows;
     const bool twist = want && pos == 0;
     const uint64_t active = __ballot(1);
     uint64_t todo = __ballot(twist);
+    if (prefetched >= 0 && !todo) __builtin_amdgcn_s_waitcnt(0);  // a forecast that did not come true (it is exact, so: never) still lands before the scratch is reused
     if (todo) {                                                   // wave-uniform
         const int lane = (int)__lane_id();
         const int nact = __popcll(active);
@@ -150,17 +170,42 @@ __device__ inline void mt_draw_row(bool want, uint32_t cursor, uint32_t* __restr
                 wave_lds_fence();
             };
             if (nact == 64) {
-                // the full wave (all but a launch's last wave): everything unrolled, the ten 256-B loads of the block issued back to back
-                // (ONE round trip to HBM instead of ten), non-temporal both ways — a block is touched once per ~3,500 steps
+                // the full wave (all but a launch's last wave): everything unrolled, non-temporal both ways — a block is touched once per
+                // ~3,500 steps
                 constexpr int R = (kMtWords + 63) / 64;
-                uint32_t w[R];
+                if (prefetched >= 0) __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): a pending LDS-DMA has landed (nothing else orders LDS accesses behind it)
+                if (src != prefetched) {
+                    // not forecast: the ten 256-B loads of the block issued back to back (ONE round trip to HBM instead of ten)
+                    uint32_t w[R];
 #pragma unroll
-                for (int r = 0; r < R; r++) { const int k = lane + 64 * r; w[r] = k < kMtWords ? __builtin_nontemporal_load(st + k) : 0u; }
+                    for (int r = 0; r < R; r++) { const int k = lane + 64 * r; w[r] = k < kMtWords ? __builtin_nontemporal_load(st + k) : 0u; }
 #pragma unroll
-                for (int r = 0; r < R; r++) { const int k = lane + 64 * r; if (k < kMtWords) lds[k] = w[r]; }
+                    for (int r = 0; r < R; r++) { const int k = lane + 64 * r; if (k < kMtWords) lds[k] = w[r]; }
+                }
+                prefetched = -1;                                       // whatever was prefetched is consumed or overwritten now
                 wave_lds_fence();
+                // Three phases instead of ten rounds: within [0, 227), [227, 454) and [454, 624) no word depends on another word of the
+                // same phase except through the OLD successor x[k+1] (read before anyone writes); the far operand x[(k+397) % 624] is old
+                // in the first phase and comes from the phase before in the other two; x[623] takes the new x[0].
+                auto phase = [&](int lo, int hi) {
+                    uint32_t v[4];
 #pragma unroll
-                for (int r = 0; r < R; r++) round(lane + 64 * r);
+                    for (int j = 0; j < 4; j++) {
+                        const int k = lo + lane + 64 * j;
+                        if (k < hi) {
+                            const int k1 = k + 1 == kMtWords ? 0 : k + 1;
+                            const int kf = k + kMtShift >= kMtWords ? k + kMtShift - kMtWords : k + kMtShift;
+                            v[j] = mt_mix(lds[k], lds[k1], lds[kf]);
+                        }
+                    }
+                    wave_lds_fence();
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const int k = lo + lane + 64 * j; if (k < hi) lds[k] = v[j]; }
+                    wave_lds_fence();
+                };
+                phase(0, kMtWords - kMtShift);
+                phase(kMtWords - kMtShift, 2 * (kMtWords - kMtShift));
+                phase(2 * (kMtWords - kMtShift), kMtWords);
 #pragma unroll
                 for (int r = 0; r < R; r++) { const int k = lane + 64 * r; if (k < kMtWords) __builtin_nontemporal_store(lds[k], st + k); }
             } else {
@@ -321,6 +366,18 @@ __device__ inline bool cartpole_step(float (&s)[4], int action, int time_step) {
     theta = theta + C::tau * theta_dot;
     theta_dot = theta_dot + C::tau * theta_acc;
     s[0] = x; s[1] = x_dot; s[2] = theta; s[3] = theta_dot;
+    return time_step == 500 || x < -C::x_thr || x > C::x_thr || theta < -C::theta_thr || theta > C::theta_thr;
+}
+// Whether the step about to be taken ends the episode, from the state BEFORE it: x and theta advance by tau times the OLD velocities
+// (cartpole.cpp:50,52), so the forecast repeats those two operations and the test exactly — it needs neither the action nor sin / cos.
+__device__ inline bool cartpole_done_ahead(const double (&s)[4], int time_step) {
+    using C = CartPoleC;
+    const double x = s[0] + (double)C::tau * s[1], theta = s[2] + (double)C::tau * s[3];
+    return time_step == 500 || x < (double)(-C::x_thr) || x > (double)C::x_thr || theta < (double)(-C::theta_thr) || theta > (double)C::theta_thr;
+}
+__device__ inline bool cartpole_done_ahead(const float (&s)[4], int time_step) {
+    using C = CartPoleC;
+    const float x = s[0] + C::tau * s[1], theta = s[2] + C::tau * s[3];
     return time_step == 500 || x < -C::x_thr || x > C::x_thr || theta < -C::theta_thr || theta > C::theta_thr;
 }
 // mountain_car.cpp:17-36 (A2): float constants widened on use.
@@ -651,10 +708,10 @@ template <int KIND, bool LOCKSTEP, typename ActT, bool NORM, bool NT, int KEEP, 
 #ifndef GYMHIP_STEP_WAVES
 #define GYMHIP_STEP_WAVES 1   // experiment knob: min waves per SIMD the step kernel is compiled for (caps its VGPRs)
 #endif
-__global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const StepParams p) {
+__global__ __launch_bounds__(kBlock, MT ? 4 : GYMHIP_STEP_WAVES) void step_kernel(const StepParams p) {   // MT: held to 128 VGPRs (4 waves per SIMD)
     static_assert(!MT || KIND == KIND_CARTPOLE, "only CartPole draws its reset state");
     constexpr int F = EnvTraits<KIND>::F;
-    __shared__ uint32_t mt_lds[MT ? kBlock / 64 : 1][MT ? kMtWords : 1];   // one generator block per wave (mt_draw_row)
+    __shared__ __align__(16) uint32_t mt_lds[MT ? kBlock / 64 : 1][MT ? kMtWords : 1];   // one generator block per wave (mt_draw_row; 16-B aligned rows for the LDS-DMA)
     ResetSource rs{};
     if constexpr (KIND == KIND_CARTPOLE && !MT) rs = *p.src;   // uniform, issued with the first loads; only the reset path uses it
     using T = typename std::conditional<LOCKSTEP, double, float>::type;
@@ -732,6 +789,14 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
         // auto_reset off: an env that finished and has not been reset (gymhip_reset_index) is frozen — stepping it is the
         // misuse the reference reports on stderr (monitor.h:75-77); state and record stay, reward 0, done 1, error bit 3
         const bool frozen = !auto_reset && (w >> 31);
+        int mt_ahead = -1;
+        if constexpr (MT) {
+            // an env whose next reset needs row 0 regenerates its block first: forecast it here, so that the block is already on its way
+            // into LDS while the dynamics run
+            bool ahead = false;
+            if (auto_reset && cursor % (uint32_t)kMtRows == 0u) ahead = (time_limit && t + 1 >= p.max_episode_steps) || cartpole_done_ahead(s, t);
+            mt_ahead = mt_prefetch_block(ahead, p.mt_state, i, mt_lds[threadIdx.x >> 6]);
+        }
         bool env_done = false;
         if (!frozen) {
             if constexpr (KIND == KIND_CARTPOLE) env_done = cartpole_step(s, action, t); else env_done = mountaincar_step(s, action);
@@ -744,7 +809,7 @@ __global__ __launch_bounds__(kBlock, GYMHIP_STEP_WAVES) void step_kernel(const S
         if (frozen) { atomicOr(p.error_flag, 8); t = CounterWord<KIND>::steps_field(w); done = true; trunc = (w >> 30) & 1u; reward = 0.f; }
 
         uint32_t mt_raw[4];
-        if constexpr (MT) mt_draw_row(done && !frozen && auto_reset, cursor, p.mt_state, i, mt_lds[threadIdx.x >> 6], mt_raw);   // wave-collective
+        if constexpr (MT) mt_draw_row(done && !frozen && auto_reset, cursor, p.mt_state, i, mt_lds[threadIdx.x >> 6], mt_raw, mt_ahead);   // wave-collective
         if (done && !frozen) {
             // Monitor (monitor.h:78-97): every step of these envs pays the same reward, so the ordered float sum
             // of t copies equals float(t)*reward exactly (t < 2^24).  The finished episode's (length, truncated)
