@@ -117,9 +117,6 @@ __host__ __device__ inline uint32_t mt_mix(uint32_t cur, uint32_t nxt, uint32_t 
 }
 __device__ inline void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
-// Collective over the ACTIVE lanes of a wave (call it from converged code).  A lane with `want` gets the four raw (tempered)
-// outputs of its env's next reset row in `raw`; `cursor` = rows its env has consumed so far (mod kMtCursorPeriod).
-// `lds` = this wave's private 624-word scratch.
 // Starts reading one env's generator block into the wave's LDS scratch WITHOUT holding registers (LDS-DMA: three 16-B-per-lane
 // global_load_lds, non-temporal), for the first lane with `likely` — the caller's exact forecast, made before the dynamics, that the lane
 // will need a twist at the end of this step — so that the block's HBM round trip runs under the step's arithmetic instead of stalling
@@ -138,6 +135,9 @@ __device__ inline int mt_prefetch_block(bool likely, const uint32_t* __restrict_
     return src;
 }
 
+// Collective over the ACTIVE lanes of a wave (call it from converged code).  A lane with `want` gets the four raw (tempered)
+// outputs of its env's next reset row in `raw`; `cursor` = rows its env has consumed so far (mod kMtCursorPeriod).
+// `lds` = this wave's private 624-word scratch.
 template <bool SAME_LAUNCH_WRITES = false>   // true (rollout kernel): an env's block may have been rewritten earlier in this launch, by other lanes
 __device__ inline void mt_draw_row(bool want, uint32_t cursor, uint32_t* __restrict__ mt_state, int64_t i, uint32_t* lds, uint32_t (&raw)[4],
                                    int prefetched = -1) {   // prefetched: the lane whose block mt_prefetch_block has on its way into `lds`
@@ -155,7 +155,7 @@ __device__ inline void mt_draw_row(bool want, uint32_t cursor, uint32_t* __restr
             todo &= todo - 1;
             const int64_t ei = ((int64_t)__shfl((int)(i >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)i, src);
             uint32_t* st = mt_state + ei * kMtWords;
-            // Rounds of `nact` consecutive words in increasing order; within a round every lane reads its three operands before any
+            // Partial waves (a launch's last wave, single-env kernels): rounds of `nact` consecutive words in increasing order; within a round every lane reads its three operands before any
             // lane writes.  That reproduces the sequential recurrence: x[k+1] is still old when x[k] is computed, and the far operand
             // x[(k+397) % 624] is old for k < 227 and already new (written >= 227 words, i.e. >= 3 rounds, earlier) for k >= 227.
             auto round = [&](int k) {
