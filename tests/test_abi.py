@@ -29,6 +29,13 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert lib.gymhip_version() == 1
 
 
+def test_every_declared_symbol_is_documented_for_the_maintainer():
+    """INTEGRATION.md names every entry point (what it replaces in the reference, or what it is for)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in declared_functions() if n not in doc]
+    assert not missing, missing
+
+
 def test_struct_layout_matches_ctypes(tmp_path):
     from gym_amd import _lib as L
     prog = tmp_path / "layout.c"
