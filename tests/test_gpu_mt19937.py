@@ -195,3 +195,37 @@ def test_mt19937_engine_refuses_tapes_and_cursor_period_is_a_whole_number_of_blo
     with pytest.raises(L.GymhipError):
         eng.generate_reset_tape(8)
     assert 1_048_320 % 156 == 0 and 1_048_320 < (1 << 20)
+
+
+def test_mt19937_cursor_wraps_on_a_block_boundary_and_the_stream_goes_on(oracle):
+    """The 20-bit cursor field counts an env's reset rows modulo 1,048,320 = 6,720 blocks of 156 rows.  TimeLimit(1) makes every
+    step a reset; 130 envs (a full and a partial wave) are driven to three rows before the wrap by the rollout kernel, then across
+    it through gymhip_step: the oracle's std::mt19937 objects know nothing of any period — the device stream must simply go on
+    (row 0 after the wrap = a regeneration, like row 0 of any block), and no error bit is raised."""
+    from gym_amd import _lib as L
+    n, seed, period, chunk = 130, 21, 1_048_320, 1 << 16
+    ov = oracle.vec(CARTPOLE, n, F_TIME_LIMIT | F_MONITOR, 1)
+    ov.seed(seed)
+    eng = _engine(n, L.RESET_MT19937, 1)
+    eng.seed(seed)
+    eng.reset()
+    assert np.array_equal(eng.obs.cpu().numpy(), ov.reset())
+    done_steps, target = 0, period - 4                          # the reset consumed row 0: cursor = 1 + steps
+    zeros = torch.zeros((chunk, n), dtype=torch.uint8, device="cuda")
+    while done_steps < target:
+        k = min(chunk, target - done_steps)
+        eng.rollout(zeros[:k].contiguous())
+        r = ov.rollout(np.zeros((k, n), np.uint8), rec_reward=False, rec_done=False, rec_trunc=False)
+        assert np.array_equal(eng.obs.cpu().numpy(), r["final_obs"]), done_steps
+        done_steps += k
+    cur = eng.counters()["cursor"]
+    assert int(cur.min()) == int(cur.max()) == period - 3
+    a = torch.zeros(n, dtype=torch.int32, device="cuda")
+    seen = []
+    for t in range(160):                                        # across the wrap and through the whole first block after it
+        eng.step(a)
+        r = ov.step(np.zeros(n, np.int32), want64=True)
+        assert np.array_equal(eng.obs.cpu().numpy(), r["obs"]) and np.array_equal(eng.state_f64().cpu().numpy(), r["obs64"]), t
+        seen.append(int(eng.counters()["cursor"][0]))
+    assert seen[:5] == [period - 2, period - 1, 0, 1, 2] and seen[-1] == 157
+    assert eng.poll_error() == 0
