@@ -97,12 +97,27 @@ struct AtariParams {
 };
 
 using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
+#ifndef GYMHIP_ATARI_SDWA_MAX
+#define GYMHIP_ATARI_SDWA_MAX 1
+#endif
 __device__ inline uint32_t max_u8x4(uint32_t a, uint32_t b) {
-    // byte-wise unsigned max: even and odd bytes widened in place to two 16-bit lanes each -> v_pk_max_u16
+#if GYMHIP_ATARI_SDWA_MAX
+    // byte-wise unsigned max, one sub-dword-addressed v_max_u16 per byte: the byte selects zero-extend both sources and the result
+    // byte lands in place (the other bytes of the destination are preserved) — 4 instructions per dword with no masks, shifts or
+    // re-packing, where the v_pk_max_u16 form below needs 10.  The compiler does not form these by itself.
+    uint32_t d;
+    asm("v_max_u16_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(d) : "v"(a), "v"(b));
+    asm("v_max_u16_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:BYTE_1" : "+v"(d) : "v"(a), "v"(b));
+    asm("v_max_u16_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:BYTE_2" : "+v"(d) : "v"(a), "v"(b));
+    asm("v_max_u16_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:BYTE_3" : "+v"(d) : "v"(a), "v"(b));
+    return d;
+#else
+    // even and odd bytes widened in place to two 16-bit lanes each -> v_pk_max_u16
     const uint32_t m = 0x00FF00FFu;
     const u16x2 e = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a & m), __builtin_bit_cast(u16x2, b & m));
     const u16x2 o = __builtin_elementwise_max(__builtin_bit_cast(u16x2, (a >> 8) & m), __builtin_bit_cast(u16x2, (b >> 8) & m));
     return __builtin_bit_cast(uint32_t, e) | (__builtin_bit_cast(uint32_t, o) << 8);
+#endif
 }
 
 template <int GRAY15>
