@@ -100,6 +100,18 @@ using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
 #ifndef GYMHIP_ATARI_SDWA_MAX
 #define GYMHIP_ATARI_SDWA_MAX 1
 #endif
+#ifndef GYMHIP_ATARI_DOT4
+#define GYMHIP_ATARI_DOT4 1
+#endif
+#ifndef GYMHIP_ATARI_P2_UNROLL
+#define GYMHIP_ATARI_P2_UNROLL 1   // the resampler's row loop is NOT unrolled: two rows in flight cost 20 VGPRs, i.e. the fourth workgroup per CU
+#endif
+#ifndef GYMHIP_ATARI_J_UNROLL
+#define GYMHIP_ATARI_J_UNROLL NT
+#endif
+#ifndef GYMHIP_ATARI_UNR
+#define GYMHIP_ATARI_UNR 2   // items per thread per batch of the RGB load pipeline (two batches in flight)
+#endif
 __device__ inline uint32_t max_u8x4(uint32_t a, uint32_t b) {
 #if GYMHIP_ATARI_SDWA_MAX
     // byte-wise unsigned max, one sub-dword-addressed v_max_u16 per byte: the byte selects zero-extend both sources and the result
@@ -127,10 +139,15 @@ __device__ inline uint32_t gray_px(uint32_t r, uint32_t g, uint32_t b) {
     return (r * 4899u + g * 9617u + b * 1868u + (1u << 13)) >> 14;
 }
 
-__device__ inline uint32_t sat_u8(float v) {   // cv::saturate_cast<uchar>(float): round half to even, clamp
-    int iv = (int)rintf(v);
-    iv = iv < 0 ? 0 : (iv > 255 ? 255 : iv);
-    return (uint32_t)iv;
+// The same gray value from a pixel held as bytes R, G, B in one dword (byte 3: anything): two v_dot4_u32_u8 with the weights split
+// into their low and high bytes (w = 256 * hi + lo, so sum(c * w) = 256 * sum(c * hi) + sum(c * lo) exactly; the fourth weight byte is 0)
+// and one shift-add, instead of three byte extractions and three multiplies.
+template <int GRAY15>
+__device__ inline uint32_t gray_rgbx(uint32_t px) {
+    constexpr uint32_t wr = GRAY15 ? 9798u : 4899u, wg = GRAY15 ? 19235u : 9617u, wb = GRAY15 ? 3735u : 1868u;
+    constexpr int sh = GRAY15 ? 15 : 14;
+    constexpr uint32_t lo = (wr & 255u) | ((wg & 255u) << 8) | ((wb & 255u) << 16), hi = (wr >> 8) | ((wg >> 8) << 8) | ((wb >> 8) << 16);
+    return (__builtin_amdgcn_udot4(px, lo, 1u << (sh - 1), false) + (__builtin_amdgcn_udot4(px, hi, 0u, false) << 8)) >> sh;
 }
 
 struct u32x3 { uint32_t x, y, z; };   // 12-B load unit: 4 whole RGB pixels (the three dword loads merge into one dwordx3)
@@ -194,7 +211,7 @@ __global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preproc
 #else
                         const uint32_t m = max_u8x4(lut[(ia >> (8 * k)) & 255u], lut[(ib >> (8 * k)) & 255u]);   // cv::max of the two coloured pixels
 #endif
-                        out |= gray_px<GRAY15>(m & 255u, (m >> 8) & 255u, (m >> 16) & 255u) << (8 * k);
+                        out |= gray_rgbx<GRAY15>(m) << (8 * k);
                     }
                     g[w] = out;
                 }
@@ -205,60 +222,121 @@ __global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preproc
     const uint32_t* fa = (const uint32_t*)(p.frames + e * 2 * (int64_t)HW * 3);
     const uint32_t* fb = (const uint32_t*)(p.frames + e * 2 * (int64_t)HW * 3 + (int64_t)HW * 3);
     const int items = HW / 4;                                      // 4 pixels (12 B) per item
-    constexpr int UNR = 4;
-    for (int it = tid; it < items; it += kFrameBlock * UNR) {
-        u32x3 a[UNR], b[UNR];
+    // One item: byte-wise max of the two frames' 12 bytes, gray of the 4 pixels, one 4-B LDS store.
+    auto item = [&](int j, const u32x3& a, const u32x3& b) {
+        const uint32_t w0 = max_u8x4(a.x, b.x), w1 = max_u8x4(a.y, b.y), w2 = max_u8x4(a.z, b.z);
+        // bytes: w0 = R0 G0 B0 R1 | w1 = G1 B1 R2 G2 | w2 = B2 R3 G3 B3   (little endian)
+#if GYMHIP_ATARI_DOT4
+        const uint32_t g0 = gray_rgbx<GRAY15>(w0);                                       // v_alignbyte_b32 lines each pixel's three bytes up
+        const uint32_t g1 = gray_rgbx<GRAY15>(__builtin_amdgcn_alignbyte(w1, w0, 3));
+        const uint32_t g2 = gray_rgbx<GRAY15>(__builtin_amdgcn_alignbyte(w2, w1, 2));
+        const uint32_t g3 = gray_rgbx<GRAY15>(w2 >> 8);
+#else
+        const uint32_t g0 = gray_px<GRAY15>(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
+        const uint32_t g1 = gray_px<GRAY15>(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u);
+        const uint32_t g2 = gray_px<GRAY15>((w1 >> 16) & 255u, w1 >> 24, w2 & 255u);
+        const uint32_t g3 = gray_px<GRAY15>((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24);
+#endif
+        gray32[j] = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+    };
+    // Software pipeline over batches of UNR items per thread, two register sets in ping-pong: the next batch's loads are issued before
+    // the current batch's arithmetic, so a wave always has 2 x UNR 12-B loads in flight (the single-set form waited for a whole batch,
+    // computed, and only then issued the next).  Full batches carry no bounds checks; the ragged end goes item by item.
+    constexpr int UNR = GYMHIP_ATARI_UNR, STEP = kFrameBlock * UNR;
+    const int full_end = items - (UNR - 1) * kFrameBlock;          // it < full_end: all UNR items of the batch exist
+    auto load = [&](int it, u32x3 (&a)[UNR], u32x3 (&b)[UNR]) {
 #pragma unroll
-        for (int u = 0; u < UNR; u++) {
-            const int j = it + u * kFrameBlock;
-            if (j < items) { a[u] = load_px4(fa, j); b[u] = load_px4(fb, j); }
-        }
+        for (int u = 0; u < UNR; u++) { a[u] = load_px4(fa, it + u * kFrameBlock); b[u] = load_px4(fb, it + u * kFrameBlock); }
+    };
+    auto work = [&](int it, const u32x3 (&a)[UNR], const u32x3 (&b)[UNR]) {
 #pragma unroll
-        for (int u = 0; u < UNR; u++) {
-            const int j = it + u * kFrameBlock;
-            if (j >= items) continue;
-            const uint32_t w0 = max_u8x4(a[u].x, b[u].x), w1 = max_u8x4(a[u].y, b[u].y), w2 = max_u8x4(a[u].z, b[u].z);
-            // bytes: w0 = R0 G0 B0 R1 | w1 = G1 B1 R2 G2 | w2 = B2 R3 G3 B3   (little endian)
-            const uint32_t g0 = gray_px<GRAY15>(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
-            const uint32_t g1 = gray_px<GRAY15>(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u);
-            const uint32_t g2 = gray_px<GRAY15>((w1 >> 16) & 255u, w1 >> 24, w2 & 255u);
-            const uint32_t g3 = gray_px<GRAY15>((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24);
-            gray32[j] = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
-        }
+        for (int u = 0; u < UNR; u++) item(it + u * kFrameBlock, a[u], b[u]);
+    };
+    int it = tid;
+    u32x3 a0[UNR], b0[UNR], a1[UNR], b1[UNR];
+    if (it < full_end) load(it, a0, b0);
+    while (it < full_end) {
+        if (it + STEP < full_end) load(it + STEP, a1, b1);
+        work(it, a0, b0);
+        it += STEP;
+        if (it >= full_end) break;
+        if (it + STEP < full_end) load(it + STEP, a0, b0);
+        work(it, a1, b1);
+        it += STEP;
     }
+    for (; it < items; it += kFrameBlock) item(it, load_px4(fa, it), load_px4(fb, it));
     }
 
-    // ---- phase 2: INTER_AREA out of LDS.  A thread owns 4 horizontally adjacent output columns (its 4 x NT x-taps stay
-    // in registers) and walks down the rows; the 4 results leave as one 4-B store. -----------------------------------------
+    // ---- phase 2: INTER_AREA out of LDS.  A thread owns 4 horizontally adjacent output columns and walks down the rows; the 4 results
+    // leave as one 4-B store.  VALU-lean on purpose (the kernel overlaps this phase with other workgroups' loads, and what it costs is
+    // issue slots): an output column's x-taps are CONSECUTIVE source pixels (computeResizeAreaTab), so a column keeps one base index and
+    // its taps are immediate offsets of the LDS reads (a padded tap reads the next pixel and multiplies it by its weight 0: adds +0);
+    // columns are processed in pairs with packed fp32 multiplies and adds (v_pk_mul_f32 / v_pk_add_f32: per lane the same IEEE
+    // operations in the same order as OpenCV's scalar loop); the horizontal sum starts from the first product rather than from 0 + product
+    // (the products are >= +0, so 0 + p == p bit for bit); v_cvt_pk_u8_f32 is saturate_cast<uchar> (round half to even, clamp:
+    // tools/cvt_probe.hip) and packs the byte in the same instruction. -----------------------------------------------------------------
+    using f32x2 = float __attribute__((ext_vector_type(2)));
     const int dw4 = p.dw / 4, rows_per_pass = kFrameBlock / dw4;
     const int qx = tid % dw4, ry = tid / dw4;
-    int xs[4][NT]; float xa[4][NT];
+    int x0[4]; f32x2 xa01[NT], xa23[NT];
 #pragma unroll
-    for (int q = 0; q < 4; q++)
+    for (int q = 0; q < 4; q++) x0[q] = p.xsi[(qx * 4 + q) * kMaxT];
 #pragma unroll
-        for (int k = 0; k < NT; k++) { xs[q][k] = p.xsi[(qx * 4 + q) * kMaxT + k]; xa[q][k] = p.xal[(qx * 4 + q) * kMaxT + k]; }
+    for (int k = 0; k < NT; k++) {
+        xa01[k] = f32x2{p.xal[(qx * 4 + 0) * kMaxT + k], p.xal[(qx * 4 + 1) * kMaxT + k]};
+        xa23[k] = f32x2{p.xal[(qx * 4 + 2) * kMaxT + k], p.xal[(qx * 4 + 3) * kMaxT + k]};
+    }
     __syncthreads();
     uint32_t* dst32 = (uint32_t*)(p.out + e * p.env_stride + p.slot_offset);
 #if GYMHIP_ATARI_DIAG == 1
     if (tid < 8) dst32[tid] = gray32[tid * 64];
     return;
 #endif
+#if GYMHIP_ATARI_DIAG == 4          // no resampler: the output plane is stored from the gray image's first bytes
+    for (int k = tid; k < p.dh * dw4; k += kFrameBlock) dst32[k] = gray32[k];
+    return;
+#elif GYMHIP_ATARI_DIAG == 5        // the same, non-temporal
+    for (int k = tid; k < p.dh * dw4; k += kFrameBlock) __builtin_nontemporal_store(gray32[k], dst32 + k);
+    return;
+#elif GYMHIP_ATARI_DIAG == 6        // the same into one of 768 fixed planes (stays in L2: never reaches HBM)
+    { uint32_t* d6 = (uint32_t*)(p.out + (e % 768) * p.env_stride + p.slot_offset);
+      for (int k = tid; k < p.dh * dw4; k += kFrameBlock) d6[k] = gray32[k]; }
+    return;
+#elif GYMHIP_ATARI_DIAG == 7        // a quarter of the plane
+    for (int k = tid; k < p.dh * dw4 / 4; k += kFrameBlock) dst32[k] = gray32[k];
+    return;
+#endif
     if (ry < rows_per_pass) {
+#pragma unroll GYMHIP_ATARI_P2_UNROLL
         for (int dy = ry; dy < p.dh; dy += rows_per_pass) {
-            float sum[4];
-#pragma unroll
+            f32x2 sum01, sum23;
+#pragma unroll GYMHIP_ATARI_J_UNROLL
             for (int j = 0; j < NT; j++) {
                 const float beta = yal[dy * kMaxT + j];
                 const uint8_t* S = gray + ysi[dy * kMaxT + j] * p.W;
+                const uint8_t *c0 = S + x0[0], *c1 = S + x0[1], *c2 = S + x0[2], *c3 = S + x0[3];
+                f32x2 b01 = f32x2{(float)c0[0], (float)c1[0]} * xa01[0];
+                f32x2 b23 = f32x2{(float)c2[0], (float)c3[0]} * xa23[0];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    float buf = 0.f;
-#pragma unroll
-                    for (int k = 0; k < NT; k++) buf += (float)S[xs[q][k]] * xa[q][k];
-                    sum[q] = (j == 0) ? beta * buf : sum[q] + beta * buf;
+                for (int k = 1; k < NT; k++) {
+                    b01 = b01 + f32x2{(float)c0[k], (float)c1[k]} * xa01[k];
+                    b23 = b23 + f32x2{(float)c2[k], (float)c3[k]} * xa23[k];
                 }
+                const f32x2 bb = f32x2{beta, beta};
+                if (j == 0) { sum01 = bb * b01; sum23 = bb * b23; }
+                else { sum01 = sum01 + bb * b01; sum23 = sum23 + bb * b23; }
             }
-            dst32[dy * dw4 + qx] = sat_u8(sum[0]) | (sat_u8(sum[1]) << 8) | (sat_u8(sum[2]) << 16) | (sat_u8(sum[3]) << 24);
+            uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(sum01.x, 0u, 0u);
+            px = __builtin_amdgcn_cvt_pk_u8_f32(sum01.y, 1u, px);
+            px = __builtin_amdgcn_cvt_pk_u8_f32(sum23.x, 2u, px);
+            px = __builtin_amdgcn_cvt_pk_u8_f32(sum23.y, 3u, px);
+#if GYMHIP_ATARI_DIAG == 3      // resampler computed, (practically) nothing stored
+            if (px == 0x12345678u && p.dh == 12345) dst32[dy * dw4 + qx] = px;
+#elif GYMHIP_ATARI_OUT_NT
+            __builtin_nontemporal_store(px, dst32 + dy * dw4 + qx);
+#else
+            dst32[dy * dw4 + qx] = px;
+#endif
         }
     }
 
