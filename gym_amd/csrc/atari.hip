@@ -94,6 +94,7 @@ struct AtariParams {
     const int32_t* xsi; const float* xal;   // [dw][kMaxT]
     const int32_t* ysi; const float* yal;   // [dh][kMaxT]
     int H, W, dh, dw, n_stack, slot, clear_on_done;
+    int64_t n_frames;          // frame pairs in this launch (the persistent kernel's grid is smaller: its workgroups stride over them)
 };
 
 using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
@@ -351,6 +352,199 @@ __global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preproc
     }
 }
 
+// A workgroup barrier that orders LDS traffic only: every LDS operation of this wave has completed (lgkmcnt = 0) before it arrives.
+// __syncthreads() would also wait for the wave's outstanding GLOBAL loads and stores (vmcnt = 0) — exactly what the persistent kernel
+// below must not do: the next frame's first loads and the previous frame's output stores stay in flight across it.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The Atari geometry itself — 210 x 160 RGB screens to 84 x 84 planes (warp_frame.h:41-47 on AtariEnv's frames) — with every extent a
+// compile-time constant, as a PERSISTENT kernel: the grid is what the chip holds at once and a workgroup walks frames
+// e = blockIdx.x, += gridDim.x.  Same arithmetic as atari_preprocess_kernel, item for item; what differs is the schedule:
+//   * phase 1 is straight-line code (8 batches of 2 items per thread + a ragged item), so every s_waitcnt is an exact count;
+//   * the next frame's first batch of loads is issued BEFORE the resampler runs and lands while it computes;
+//   * the resampler leaves the finished plane in LDS and each thread sends its own four dwords to memory from INSIDE the next
+//     frame's load stream, where their acknowledgement is behind loads the wave waits for anyway (vmcnt counts in order): no
+//     workgroup ever sits at its end waiting for stores with nothing else in flight.  Only a workgroup's last plane goes out alone.
+// MI355X, 4096 envs: 0.163 ms (one workgroup per frame) -> 0.157.  Where the rest goes (FDIAG builds): loads + gray alone 0.127 ms,
+// + resampler 0.142, + the planes' stores 0.157.  The 29 MB of stores cost as much as 150 MB of loads and the cost is memory-side:
+// the same for 4-B and 16-B stores, early or late in the stream, planes on 128-B lines or not; nothing when every workgroup stores
+// into the same plane; half when a workgroup stores all its planes in one burst at its end (profiles/NOTES.md, round 3).
+struct AtariGeo {
+    static constexpr int H = 210, W = 160, DH = 84, DW = 84, HW = H * W, NT = 3;
+    static constexpr int DW4 = DW / 4;                              // 21 output dwords per row
+    static constexpr int ROWS_PER_PASS = kFrameBlock / DW4;         // 24 rows per pass of the workgroup
+    static constexpr int PASS_WORDS = ROWS_PER_PASS * DW4;          // 504 threads resample; a thread's dwords: tid, tid + 504, ..
+    static constexpr int PLANE_WORDS = DH * DW4;                    // 1764
+    static constexpr int PASSES = (PLANE_WORDS + PASS_WORDS - 1) / PASS_WORDS;   // 4 (the last one half full)
+    static constexpr int XREC = 4 + 4 * NT;                         // per column quad: 4 base indices + NT x 4 weights
+};
+
+#ifndef GYMHIP_ATARI_FDIAG
+// Timing experiments only (results WRONG; profiles/r03_atari_persistent_decomposition.txt): bit 0 = planes are not stored (but a workgroup's
+// last), bit 1 = no resampler (the plane is a copy of the gray image's first bytes), bit 2 = every workgroup stores into the same plane,
+// bit 5 = a workgroup stores all its planes in one burst when it ends.
+#define GYMHIP_ATARI_FDIAG 0
+#endif
+template <int GRAY15>
+__global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preprocess_fixed_kernel(const AtariParams p) {
+    using G = AtariGeo;
+    using f32x2 = float __attribute__((ext_vector_type(2)));
+    using f32x4 = float __attribute__((ext_vector_type(4)));
+    using i32x4 = int __attribute__((ext_vector_type(4)));
+    __shared__ __align__(16) uint32_t gray32[G::HW / 4];            // the gray image
+    __shared__ __align__(16) uint32_t stage32[G::PLANE_WORDS];      // the finished plane, parked until the next frame's loads are under way
+    __shared__ __align__(16) float xrec[G::DW4 * G::XREC];          // resampler constants per column quad
+    __shared__ __align__(16) int32_t yoff[G::DH * G::NT];           // y-taps: byte offset of the source row
+    __shared__ __align__(16) float ybeta[G::DH * G::NT];            // y-taps: weight
+    const uint8_t* gray = (const uint8_t*)gray32;
+    const int tid = threadIdx.x;
+
+    for (int k = tid; k < G::DH * G::NT; k += kFrameBlock) {
+        const int d = k / G::NT, j = k % G::NT;
+        yoff[k] = p.ysi[d * kMaxT + j] * G::W; ybeta[k] = p.yal[d * kMaxT + j];
+    }
+    // The resampler's per-thread constants live in LDS and are read back at the start of every phase 2: held in registers across
+    // phase 1 they push the kernel past 80 VGPRs, and a spilled register's reload waits for vmcnt(0) — for every load in flight.
+    for (int k = tid; k < G::DW4 * G::XREC; k += kFrameBlock) {
+        const int q = k / G::XREC, w = k % G::XREC;
+        if (w < 4) ((int32_t*)xrec)[k] = p.xsi[(q * 4 + w) * kMaxT];                  // base source index of column 4q + w (its taps are consecutive pixels)
+        else xrec[k] = p.xal[(q * 4 + ((w - 4) & 3)) * kMaxT + ((w - 4) >> 2)];     // tap (w-4)/4 of column 4q + (w-4)%4
+    }
+    __syncthreads();
+
+    // Items of 4 pixels = 12 B per frame: 8400 = 16 x 512 + 208, i.e. 16 per thread and one more for 208 threads.
+    constexpr int64_t kFrameBytes = G::HW * 3;
+    constexpr int kItems = G::HW / 4, kFull = kItems / kFrameBlock, kRagged = kItems % kFrameBlock;
+    auto load_item = [&](const uint8_t* frame, int m) { return load_px4((const uint32_t*)frame, tid + kFrameBlock * m); };   // item tid + 512 m
+    auto work_item = [&](int m, const u32x3& a, const u32x3& b) {                   // max of the two frames -> gray -> LDS
+        const uint32_t w0 = max_u8x4(a.x, b.x), w1 = max_u8x4(a.y, b.y), w2 = max_u8x4(a.z, b.z);
+        // bytes: w0 = R0 G0 B0 R1 | w1 = G1 B1 R2 G2 | w2 = B2 R3 G3 B3   (little endian); v_alignbyte_b32 lines each pixel's three bytes up
+        const uint32_t g0 = gray_rgbx<GRAY15>(w0);
+        const uint32_t g1 = gray_rgbx<GRAY15>(__builtin_amdgcn_alignbyte(w1, w0, 3));
+        const uint32_t g2 = gray_rgbx<GRAY15>(__builtin_amdgcn_alignbyte(w2, w1, 2));
+        const uint32_t g3 = gray_rgbx<GRAY15>(w2 >> 8);
+        gray32[tid + kFrameBlock * m] = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+    };
+    // Two register sets of UNR items per frame in ping-pong: set 0 takes batches 0, 2, ..; set 1 takes batches 1, 3, ..
+    constexpr int UNR = 2, kBatches = kFull / UNR;
+    static_assert(kFull % UNR == 0 && kBatches % 2 == 0, "phase 1 is written for an even number of full batches");
+    u32x3 a0[UNR], b0[UNR], a1[UNR], b1[UNR];
+    auto load_batch = [&](const uint8_t* fa, int batch, u32x3 (&a)[UNR], u32x3 (&b)[UNR]) {
+#pragma unroll
+        for (int u = 0; u < UNR; u++) { a[u] = load_item(fa, batch * UNR + u); b[u] = load_item(fa + kFrameBytes, batch * UNR + u); }
+    };
+    auto work_batch = [&](int batch, const u32x3 (&a)[UNR], const u32x3 (&b)[UNR]) {
+#pragma unroll
+        for (int u = 0; u < UNR; u++) work_item(batch * UNR + u, a[u], b[u]);
+    };
+    // The parked plane goes to memory: four dwords per thread (504 threads; the fourth for half of them).
+    auto flush = [&](uint32_t* dst) {
+        if (tid < G::PASS_WORDS) {
+#pragma unroll
+            for (int n = 0; n < G::PASSES; n++)
+                if ((n + 1) * G::PASS_WORDS <= G::PLANE_WORDS || tid + n * G::PASS_WORDS < G::PLANE_WORDS) dst[tid + n * G::PASS_WORDS] = stage32[tid + n * G::PASS_WORDS];
+        }
+    };
+
+    int64_t e = blockIdx.x;
+    if (e >= p.n_frames) return;
+    load_batch(p.frames + e * 2 * kFrameBytes, 0, a0, b0);
+    uint32_t* pend = nullptr;                                      // where the parked plane belongs (null: nothing parked)
+#if GYMHIP_ATARI_FDIAG & 32
+    __shared__ uint32_t* pend_list[64];
+    int n_pend = 0;
+#endif
+    for (;;) {
+        const uint8_t* fa = p.frames + e * 2 * kFrameBytes;
+        // the done flag is read up here, in front of the load stream: read after the resampler, its wait (vmcnt counts in order) would also be a wait for the next frame's first batch
+        const bool clear = p.clear_on_done && p.ring && p.done && p.done[e];
+        // ---- phase 1: max of the two frames -> gray -> LDS; set 0 holds batch 0 already ---------------------------------
+#pragma unroll
+        for (int b = 0; b < kBatches; b += 2) {
+            load_batch(fa, b + 1, a1, b1);
+#if !(GYMHIP_ATARI_FDIAG & (1 | 32))
+            if (b == 0 && pend) flush(pend);                       // the previous frame's plane leaves between this frame's 2nd and 3rd batch
+#endif
+            work_batch(b, a0, b0);
+            if (b + 2 < kBatches) load_batch(fa, b + 2, a0, b0);
+            else if (kRagged && tid < kRagged) { a0[0] = load_item(fa, kFull); b0[0] = load_item(fa + kFrameBytes, kFull); }
+            work_batch(b + 1, a1, b1);
+        }
+        if (kRagged && tid < kRagged) work_item(kFull, a0[0], b0[0]);
+        lds_barrier();                                             // the gray image is complete
+
+        const int64_t en = e + gridDim.x;
+        const bool more = en < p.n_frames;
+        if (more) load_batch(p.frames + en * 2 * kFrameBytes, 0, a0, b0);   // rides across the resampler
+
+        // ---- phase 2: INTER_AREA out of LDS into the parked plane (see atari_preprocess_kernel for the arithmetic) -------
+        if (tid < G::PASS_WORDS && !(GYMHIP_ATARI_FDIAG & 2)) {
+            const int qx = tid % G::DW4, ry = tid / G::DW4;
+            const i32x4 x0 = *(const i32x4*)(xrec + qx * G::XREC);
+            f32x2 xa01[G::NT], xa23[G::NT];
+#pragma unroll
+            for (int k = 0; k < G::NT; k++) {
+                const f32x4 t = *(const f32x4*)(xrec + qx * G::XREC + 4 + 4 * k);
+                xa01[k] = f32x2{t.x, t.y}; xa23[k] = f32x2{t.z, t.w};
+            }
+#pragma unroll 1
+            for (int dy = ry; dy < G::DH; dy += G::ROWS_PER_PASS) {
+                f32x2 sum01, sum23;
+#pragma unroll 1
+                for (int j = 0; j < G::NT; j++) {
+                    const float beta = ybeta[dy * G::NT + j];
+                    const uint8_t* S = gray + yoff[dy * G::NT + j];
+                    const uint8_t *c0 = S + x0[0], *c1 = S + x0[1], *c2 = S + x0[2], *c3 = S + x0[3];
+                    f32x2 b01 = f32x2{(float)c0[0], (float)c1[0]} * xa01[0];
+                    f32x2 b23 = f32x2{(float)c2[0], (float)c3[0]} * xa23[0];
+#pragma unroll
+                    for (int k = 1; k < G::NT; k++) {
+                        b01 = b01 + f32x2{(float)c0[k], (float)c1[k]} * xa01[k];
+                        b23 = b23 + f32x2{(float)c2[k], (float)c3[k]} * xa23[k];
+                    }
+                    const f32x2 bb = f32x2{beta, beta};
+                    if (j == 0) { sum01 = bb * b01; sum23 = bb * b23; }
+                    else { sum01 = sum01 + bb * b01; sum23 = sum23 + bb * b23; }
+                }
+                uint32_t px = __builtin_amdgcn_cvt_pk_u8_f32(sum01.x, 0u, 0u);
+                px = __builtin_amdgcn_cvt_pk_u8_f32(sum01.y, 1u, px);
+                px = __builtin_amdgcn_cvt_pk_u8_f32(sum23.x, 2u, px);
+                px = __builtin_amdgcn_cvt_pk_u8_f32(sum23.y, 3u, px);
+                stage32[dy * G::DW4 + qx] = px;                    // = stage32[tid + pass * PASS_WORDS]: read back by this thread only
+            }
+        }
+#if GYMHIP_ATARI_FDIAG & 2
+        if (tid < G::PASS_WORDS) for (int n = 0; n < 3; n++) stage32[tid + n * G::PASS_WORDS] = gray32[tid + n * G::PASS_WORDS];
+#endif
+        pend = (uint32_t*)(p.out + e * p.env_stride + p.slot_offset);
+#if GYMHIP_ATARI_FDIAG & 4
+        pend = (uint32_t*)(p.out + p.slot_offset);
+#endif
+
+        // ---- optional SB3-style clear of the older planes when the env finished an episode --------------------------
+        if (clear) {
+            for (int s = 0; s < p.n_stack; s++) {
+                if (s == p.slot) continue;
+                uint32_t* pl = (uint32_t*)(p.ring + (e * p.n_stack + s) * (int64_t)(G::DH * G::DW));
+                for (int k = tid; k < G::PLANE_WORDS; k += kFrameBlock) pl[k] = 0u;
+            }
+        }
+#if GYMHIP_ATARI_FDIAG & 32
+        if (tid == 0 && n_pend < 64) pend_list[n_pend] = pend;
+        n_pend++;
+#endif
+        if (!more) break;
+        lds_barrier();                                             // every wave is done reading the gray image: the next frame may overwrite it
+        e = en;
+    }
+#if GYMHIP_ATARI_FDIAG & 32
+    __syncthreads();
+    for (int i = 0; i < n_pend && i < 64; i++) flush(pend_list[i]);
+    return;
+#endif
+    flush(pend);                                                   // the workgroup's last plane
+}
+
 // VecFrameStack on its own: planes that are ALREADY dst_h x dst_w gray images go into ring slot `slot` (one workgroup per env
 // plane, 4-B units: dst_w % 4 == 0), with the same optional clear of a finished env's older planes as the fused kernel.
 __global__ __launch_bounds__(kBlock) void push_planes_kernel(const uint32_t* __restrict__ planes, uint8_t* ring, int64_t n, int plane4, int k, int slot,
@@ -567,6 +761,8 @@ struct gymhip_atari {
     int64_t updates_since_reset;   // VecFrameStack::stepWait calls since the last reset (the as-written view needs 0 / 1 / more)
     int view;                      // GYMHIP_STACK_INTENDED | GYMHIP_STACK_AS_WRITTEN
     uint32_t* lut;        // INDEX8 colour table (device, 256 entries R | G<<8 | B<<16) or null until gymhip_atari_set_palette
+    bool fixed_geo;       // 210 x 160 -> 84 x 84 with <= 3 taps: RGB24 frames go through atari_preprocess_fixed_kernel (persistent)
+    int persist_grid;     // workgroups of that kernel the chip holds at once: its grid
 };
 
 namespace {
@@ -586,10 +782,27 @@ template <typename T> int upload(const std::vector<T>& v, T** out) {
     return GYMHIP_OK;
 }
 
+const void* fixed_kernel_of(const gymhip_atari* h) {
+    return h->cfg.gray_bits == 15 ? (const void*)atari_preprocess_fixed_kernel<1> : (const void*)atari_preprocess_fixed_kernel<0>;
+}
+
+// GYMHIP_ATARI_GENERIC=1 sends the Atari geometry through the generic kernel too; GYMHIP_ATARI_GRID overrides the persistent grid
+// (sweeps and tests; both are read at every launch).
 template <int SRC>
-void launch_variant(gymhip_atari* h, const AtariParams& p, hipStream_t s) {
+void launch_variant(gymhip_atari* h, AtariParams p, hipStream_t s) {
     dim3 grid((unsigned)h->cfg.n_envs), block(kFrameBlock);
     const bool g15 = h->cfg.gray_bits == 15;
+    const char* ge = getenv("GYMHIP_ATARI_GENERIC");
+    const bool force_generic = ge && atoi(ge) != 0;
+    if (SRC == 0 && h->fixed_geo && !force_generic) {
+        p.n_frames = h->cfg.n_envs;
+        int64_t g = h->persist_grid;
+        if (const char* e = getenv("GYMHIP_ATARI_GRID")) { const long v = atol(e); if (v > 0) g = v; }
+        g = std::max<int64_t>(1, std::min<int64_t>(g, p.n_frames));
+        void* args[] = {(void*)&p};
+        (void)hipLaunchKernel(fixed_kernel_of(h), dim3((unsigned)g), block, args, 0, s);   // the caller checks hipGetLastError
+        return;
+    }
     if (h->max_taps <= 3) {
         if (g15) hipLaunchKernelGGL((atari_preprocess_kernel<1, 3, SRC>), grid, block, h->lds_bytes, s, p);
         else hipLaunchKernelGGL((atari_preprocess_kernel<0, 3, SRC>), grid, block, h->lds_bytes, s, p);
@@ -714,6 +927,15 @@ int gymhip_atari_create(const gymhip_atari_config* cfg, int device, gymhip_atari
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess)
                 rc = fail(GYMHIP_EHIP, "cannot raise the dynamic LDS limit to %zu B", h->lds_bytes);
+    }
+    h->fixed_geo = cfg->src_h == AtariGeo::H && cfg->src_w == AtariGeo::W && cfg->dst_h == AtariGeo::DH && cfg->dst_w == AtariGeo::DW && h->max_taps <= AtariGeo::NT;
+    if (!rc && h->fixed_geo) {
+        hipDeviceProp_t prop;
+        hipError_t e = hipGetDeviceProperties(&prop, device);
+        int per_cu = 0;
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fixed_kernel_of(h), kFrameBlock, 0);
+        h->persist_grid = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
+        if (e != hipSuccess) rc = fail(GYMHIP_EHIP, "occupancy query for the preprocess kernel failed: %s", hipGetErrorString(e));
     }
     if (rc) { gymhip_atari_destroy(h); return rc; }
     *out = h;

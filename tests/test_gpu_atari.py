@@ -199,6 +199,34 @@ def test_clear_on_done_option():
     assert np.array_equal(a[d][..., -1], b[d][..., -1]) and (a[d][..., :-1] == 0).all() and (b[d][..., :-1] != 0).any()
 
 
+@pytest.mark.parametrize("grid", [1, 3, 5, 64])
+def test_persistent_kernel_walks_frames_exactly(oracle, monkeypatch, grid):
+    """The Atari geometry's RGB path is a persistent kernel (atari_preprocess_fixed_kernel): a workgroup walks frames
+    blockIdx, += grid, parks each finished plane in LDS and stores it from inside the next frame's load stream.  With the
+    grid forced small (GYMHIP_ATARI_GRID, read per launch) one workgroup handles many frames — 1 workgroup for all 13,
+    uneven shares, more workgroups than frames — and every plane must still be the oracle's, in the right ring slot, with
+    clear-on-done applied to the right envs."""
+    from gym_amd.atari import AtariPreprocessor
+    monkeypatch.setenv("GYMHIP_ATARI_GRID", str(grid))
+    n = 13
+    f0, f1 = counter_frames(21, n, 0), counter_frames(21, n, 1)
+    f0[:8] = structured_frames()
+    pp = AtariPreprocessor(n, clear_on_done=True)
+    assert np.array_equal(pp.preprocess(torch.from_numpy(f0).cuda()).cpu().numpy(), oracle.atari_preprocess(f0))
+    stack = np.zeros((n, 84, 84, 4), np.uint8)
+    pp.reset(torch.from_numpy(f0).cuda())
+    oracle.framestack_reset(stack, oracle.atari_preprocess(f0))
+    done = np.zeros(n, np.uint8); done[[0, 4, 12]] = 1
+    pp.step(torch.from_numpy(f1).cuda(), torch.from_numpy(done).cuda())
+    oracle.framestack_update(stack, oracle.atari_preprocess(f1))
+    stack[done.astype(bool), :, :, :-1] = 0
+    assert np.array_equal(pp.stacked_nhwc().cpu().numpy(), stack)
+    # the generic kernel (one workgroup per frame; GYMHIP_ATARI_GENERIC is read per launch too) on the same frames: identical planes
+    fixed = pp.preprocess(torch.from_numpy(f1).cuda()).clone()
+    monkeypatch.setenv("GYMHIP_ATARI_GENERIC", "1")
+    assert torch.equal(pp.preprocess(torch.from_numpy(f1).cuda()), fixed)
+
+
 def test_config4_full_size_properties():
     """BASELINE config 4 at full size (4096 envs, 826 MB of frames): size-independent properties —
     (1) every env given the same frame pair yields the same 84x84 image (and equals the small-batch result);

@@ -9,7 +9,7 @@ import torch
 
 from gym_amd.atari import AtariPreprocessor
 
-n = 4096
+n = int(os.environ.get("ATARI_N", 4096))   # ATARI_N / ATARI_RGB_ONLY: sweeps
 pp = AtariPreprocessor(n)
 pp.set_palette(np.random.default_rng(0).integers(0, 1 << 24, 256, dtype=np.uint32))
 
@@ -31,6 +31,8 @@ def timed(x, bytes_per_env, label, steps=50):
 rgb = torch.randint(0, 256, (n, 2, 210, 160, 3), dtype=torch.uint8, device="cuda")
 timed(rgb, 208656, "rgb frames")
 del rgb
+if os.environ.get("ATARI_RGB_ONLY"):
+    sys.exit(0)
 idx = torch.randint(0, 128, (n, 2, 210, 160), dtype=torch.uint8, device="cuda") * 2
 timed(idx, 74256, "index screens, random")
 blocks = torch.randint(0, 128, (n, 2, 14, 10), dtype=torch.uint8, device="cuda") * 2
