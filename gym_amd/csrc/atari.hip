@@ -352,6 +352,15 @@ __global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preproc
     }
 }
 
+// Item tid + 512 m of a frame, addressed as (uniform base + 6144 m) + 12 tid with the uniform part pinned in SGPRs (the empty asm makes
+// it opaque): left alone, the compiler folds each load's constant into a VGPR offset of its own and hoists them all out of the frame
+// loop — one VGPR per load of the unrolled pipeline, 15 of the kernel's 80.  This way every load shares the one offset register.
+__device__ inline u32x3 load_px4_uniform_base(const uint8_t* frame, int m, int tid) {
+    const uint8_t* base = frame + (int64_t)m * (kFrameBlock * 12);
+    asm("" : "+s"(base));
+    return load_px4((const uint32_t*)base, tid);
+}
+
 // A workgroup barrier that orders LDS traffic only: every LDS operation of this wave has completed (lgkmcnt = 0) before it arrives.
 // __syncthreads() would also wait for the wave's outstanding GLOBAL loads and stores (vmcnt = 0) — exactly what the persistent kernel
 // below must not do: the next frame's first loads and the previous frame's output stores stay in flight across it.
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preproc
     // Items of 4 pixels = 12 B per frame: 8400 = 16 x 512 + 208, i.e. 16 per thread and one more for 208 threads.
     constexpr int64_t kFrameBytes = G::HW * 3;
     constexpr int kItems = G::HW / 4, kFull = kItems / kFrameBlock, kRagged = kItems % kFrameBlock;
-    auto load_item = [&](const uint8_t* frame, int m) { return load_px4((const uint32_t*)frame, tid + kFrameBlock * m); };   // item tid + 512 m
+    auto load_item = [&](const uint8_t* frame, int m) { return load_px4_uniform_base(frame, m, tid); };   // item tid + 512 m
     auto work_item = [&](int m, const u32x3& a, const u32x3& b) {                   // max of the two frames -> gray -> LDS
         const uint32_t w0 = max_u8x4(a.x, b.x), w1 = max_u8x4(a.y, b.y), w2 = max_u8x4(a.z, b.z);
         // bytes: w0 = R0 G0 B0 R1 | w1 = G1 B1 R2 G2 | w2 = B2 R3 G3 B3   (little endian); v_alignbyte_b32 lines each pixel's three bytes up
