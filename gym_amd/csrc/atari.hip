@@ -473,6 +473,8 @@ __global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preproc
             load_batch(fa, b + 1, a1, b1);
 #if !(GYMHIP_ATARI_FDIAG & (1 | 32))
             if (b == 0 && pend) flush(pend);                       // the previous frame's plane leaves between this frame's 2nd and 3rd batch
+#elif defined(GYMHIP_ATARI_BURST)   // with bit 5: the planes leave in bursts of GYMHIP_ATARI_BURST instead of all at the end
+            if (b == 0 && n_pend >= GYMHIP_ATARI_BURST) { for (int i = 0; i < n_pend; i++) flush(pend_list[i]); n_pend = 0; }
 #endif
             work_batch(b, a0, b0);
             if (b + 2 < kBatches) load_batch(fa, b + 2, a0, b0);
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preproc
             }
         }
 #if GYMHIP_ATARI_FDIAG & 2
-        if (tid < G::PASS_WORDS) for (int n = 0; n < 3; n++) stage32[tid + n * G::PASS_WORDS] = gray32[tid + n * G::PASS_WORDS];
+        for (int k = tid; k < G::PLANE_WORDS; k += kFrameBlock) stage32[k] = gray32[k];
 #endif
         pend = (uint32_t*)(p.out + e * p.env_stride + p.slot_offset);
 #if GYMHIP_ATARI_FDIAG & 4
