@@ -11,7 +11,9 @@
 // coalesced), takes the byte-wise max, converts to 8-bit gray and parks the gray image (33.6 KB) in LDS.  Phase 2 runs
 // OpenCV's area resampler out of LDS (per-axis decimation tables, float accumulation in OpenCV's order, round-half-even
 // saturate) and writes the 84x84 result straight into the env's ring-buffer plane: HBM sees each input byte once and
-// 7,056 output bytes per env — 208,656 B per env-step, the algorithmic minimum.
+// 7,056 output bytes per env — 208,656 B per env-step, the algorithmic minimum.  Two kernels share that arithmetic:
+// atari_preprocess_kernel (any geometry, RGB24 frames or palette-index screens, one workgroup per frame) and
+// atari_preprocess_fixed_kernel (RGB 210x160 -> 84x84 with compile-time extents, persistent workgroups that walk the frames).
 //
 // -ffp-contract=off (Makefile) keeps the resampler's mul/add separate, as OpenCV's baseline x86-64 build does.
 #include <hip/hip_runtime.h>
@@ -38,10 +40,6 @@ constexpr size_t kRingKeepBytes = (size_t)240 << 20;   // a ring up to this size
 constexpr int kFrameBlock = 512;  // one workgroup per frame: 8 waves; 4 workgroups (37 KB LDS each) fill a CU's 32 wave slots
 #ifndef GYMHIP_ATARI_WAVES
 #define GYMHIP_ATARI_WAVES 6   // min waves/SIMD: 80 VGPRs -> 3 frames (24 waves) per CU; 4 = 4.67 TB/s, 6 = 5.14, 8 spills = 3.5 (profiles/r01_sweep.txt)
-#endif
-// GYMHIP_ATARI_DIAG (timing experiments only, results WRONG): 1 = phase 1 only (no resize), 2 = no colour-table lookups
-#ifndef GYMHIP_ATARI_DIAG
-#define GYMHIP_ATARI_DIAG 0
 #endif
 constexpr int kMaxT = 4;        // taps per destination index in the padded tables (zero-weight padding)
 
@@ -100,9 +98,6 @@ struct AtariParams {
 using u16x2 = unsigned short __attribute__((ext_vector_type(2)));
 #ifndef GYMHIP_ATARI_SDWA_MAX
 #define GYMHIP_ATARI_SDWA_MAX 1
-#endif
-#ifndef GYMHIP_ATARI_DOT4
-#define GYMHIP_ATARI_DOT4 1
 #endif
 #ifndef GYMHIP_ATARI_P2_UNROLL
 #define GYMHIP_ATARI_P2_UNROLL 1   // the resampler's row loop is NOT unrolled: two rows in flight cost 20 VGPRs, i.e. the fourth workgroup per CU
@@ -207,11 +202,7 @@ __global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preproc
                     uint32_t out = 0;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-#if GYMHIP_ATARI_DIAG == 2
-                        const uint32_t m = max_u8x4((ia >> (8 * k)) * 0x010101u, (ib >> (8 * k)) * 0x010101u);
-#else
                         const uint32_t m = max_u8x4(lut[(ia >> (8 * k)) & 255u], lut[(ib >> (8 * k)) & 255u]);   // cv::max of the two coloured pixels
-#endif
                         out |= gray_rgbx<GRAY15>(m) << (8 * k);
                     }
                     g[w] = out;
@@ -227,17 +218,10 @@ __global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preproc
     auto item = [&](int j, const u32x3& a, const u32x3& b) {
         const uint32_t w0 = max_u8x4(a.x, b.x), w1 = max_u8x4(a.y, b.y), w2 = max_u8x4(a.z, b.z);
         // bytes: w0 = R0 G0 B0 R1 | w1 = G1 B1 R2 G2 | w2 = B2 R3 G3 B3   (little endian)
-#if GYMHIP_ATARI_DOT4
         const uint32_t g0 = gray_rgbx<GRAY15>(w0);                                       // v_alignbyte_b32 lines each pixel's three bytes up
         const uint32_t g1 = gray_rgbx<GRAY15>(__builtin_amdgcn_alignbyte(w1, w0, 3));
         const uint32_t g2 = gray_rgbx<GRAY15>(__builtin_amdgcn_alignbyte(w2, w1, 2));
         const uint32_t g3 = gray_rgbx<GRAY15>(w2 >> 8);
-#else
-        const uint32_t g0 = gray_px<GRAY15>(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
-        const uint32_t g1 = gray_px<GRAY15>(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u);
-        const uint32_t g2 = gray_px<GRAY15>((w1 >> 16) & 255u, w1 >> 24, w2 & 255u);
-        const uint32_t g3 = gray_px<GRAY15>((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24);
-#endif
         gray32[j] = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
     };
     // Software pipeline over batches of UNR items per thread, two register sets in ping-pong: the next batch's loads are issued before
@@ -289,24 +273,6 @@ __global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preproc
     }
     __syncthreads();
     uint32_t* dst32 = (uint32_t*)(p.out + e * p.env_stride + p.slot_offset);
-#if GYMHIP_ATARI_DIAG == 1
-    if (tid < 8) dst32[tid] = gray32[tid * 64];
-    return;
-#endif
-#if GYMHIP_ATARI_DIAG == 4          // no resampler: the output plane is stored from the gray image's first bytes
-    for (int k = tid; k < p.dh * dw4; k += kFrameBlock) dst32[k] = gray32[k];
-    return;
-#elif GYMHIP_ATARI_DIAG == 5        // the same, non-temporal
-    for (int k = tid; k < p.dh * dw4; k += kFrameBlock) __builtin_nontemporal_store(gray32[k], dst32 + k);
-    return;
-#elif GYMHIP_ATARI_DIAG == 6        // the same into one of 768 fixed planes (stays in L2: never reaches HBM)
-    { uint32_t* d6 = (uint32_t*)(p.out + (e % 768) * p.env_stride + p.slot_offset);
-      for (int k = tid; k < p.dh * dw4; k += kFrameBlock) d6[k] = gray32[k]; }
-    return;
-#elif GYMHIP_ATARI_DIAG == 7        // a quarter of the plane
-    for (int k = tid; k < p.dh * dw4 / 4; k += kFrameBlock) dst32[k] = gray32[k];
-    return;
-#endif
     if (ry < rows_per_pass) {
 #pragma unroll GYMHIP_ATARI_P2_UNROLL
         for (int dy = ry; dy < p.dh; dy += rows_per_pass) {
@@ -331,13 +297,7 @@ __global__ __launch_bounds__(kFrameBlock, GYMHIP_ATARI_WAVES) void atari_preproc
             px = __builtin_amdgcn_cvt_pk_u8_f32(sum01.y, 1u, px);
             px = __builtin_amdgcn_cvt_pk_u8_f32(sum23.x, 2u, px);
             px = __builtin_amdgcn_cvt_pk_u8_f32(sum23.y, 3u, px);
-#if GYMHIP_ATARI_DIAG == 3      // resampler computed, (practically) nothing stored
-            if (px == 0x12345678u && p.dh == 12345) dst32[dy * dw4 + qx] = px;
-#elif GYMHIP_ATARI_OUT_NT
-            __builtin_nontemporal_store(px, dst32 + dy * dw4 + qx);
-#else
             dst32[dy * dw4 + qx] = px;
-#endif
         }
     }
 
