@@ -283,7 +283,9 @@ int gymhip_atari_stack_buffer(gymhip_atari* h, uint8_t** ring, int32_t* head);
  *   _reset: VecFrameStack::reset (vec_frame_stack.cpp:22-25; stacked_observation.h:106-109): zero the stack, newest last.
  *   _step:  VecFrameStack::stepWait (vec_frame_stack.cpp:27-32): shift by one frame, write the newest (INTENDED
  *           semantics of stacked_observation.h:126-130 — the reference as written mis-indexes the write).
- *           `done` (device u8 [n_envs], may be NULL) only matters with clear_on_done. */
+ *           `done` (device u8 [n_envs], may be NULL) only matters with clear_on_done.
+ * None of these allocates or synchronises.  The ring's `head` is host state, advanced by _step / _push: under HIP graph capture record
+ * n_stack consecutive steps (a whole revolution of the ring), not one — a single recorded step replays into the same slot. */
 int gymhip_atari_preprocess(gymhip_atari* h, const uint8_t* frames, uint8_t* out, void* stream);
 int gymhip_atari_reset(gymhip_atari* h, const uint8_t* frames, void* stream);
 int gymhip_atari_step(gymhip_atari* h, const uint8_t* frames, const uint8_t* done, void* stream);

@@ -227,6 +227,51 @@ def test_persistent_kernel_walks_frames_exactly(oracle, monkeypatch, grid):
     assert torch.equal(pp.preprocess(torch.from_numpy(f1).cuda()), fixed)
 
 
+def test_a_recorded_ring_revolution_replays_like_eager_steps():
+    """HIP graph capture of the image path.  The ring's `head` is HOST state (gymhip.h), so a recording of one step would
+    replay into the same slot; a recording of n_stack consecutive steps — a whole revolution, each with its NCHW view — leaves
+    `head` where it was and replays coherently.  The calls neither allocate nor synchronise, so capture succeeds; two replays
+    over fresh frames equal eager stepping bit for bit (persistent kernel included: 13 envs, forced grid of 5 workgroups)."""
+    import os
+    from gym_amd.atari import AtariPreprocessor
+    n, k = 13, 4
+    os.environ["GYMHIP_ATARI_GRID"] = "5"
+    try:
+        pp, ref = AtariPreprocessor(n, n_stack=k), AtariPreprocessor(n, n_stack=k)
+        f0 = torch.from_numpy(counter_frames(31, n, 0)).cuda()
+        pp.reset(f0); ref.reset(f0)
+        fbuf = [torch.empty_like(f0) for _ in range(k)]
+        out = [torch.empty((n, k, 84, 84), dtype=torch.float32, device="cuda") for _ in range(k)]
+        t = 1
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                                   # warm-up revolution on the capture stream, eager
+            for j in range(k):
+                fbuf[j].copy_(torch.from_numpy(counter_frames(31, n, t + j)).cuda())
+                pp.step(fbuf[j]); pp.stacked_nchw_f32(out[j])
+                ref.step(fbuf[j])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        t += k
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for j in range(k):
+                pp.step(fbuf[j]); pp.stacked_nchw_f32(out[j])
+        for _ in range(2):
+            for j in range(k):
+                fbuf[j].copy_(torch.from_numpy(counter_frames(31, n, t + j)).cuda())
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            for j in range(k):
+                ref.step(fbuf[j])
+                assert torch.equal(out[j], ref.stacked_nchw_f32()), (t, j)
+            t += k
+        assert torch.equal(pp.stacked_nhwc(), ref.stacked_nhwc())
+    finally:
+        del os.environ["GYMHIP_ATARI_GRID"]
+
+
 def test_config4_full_size_properties():
     """BASELINE config 4 at full size (4096 envs, 826 MB of frames): size-independent properties —
     (1) every env given the same frame pair yields the same 84x84 image (and equals the small-batch result);
