@@ -227,6 +227,25 @@ def test_persistent_kernel_walks_frames_exactly(oracle, monkeypatch, grid):
     assert torch.equal(pp.preprocess(torch.from_numpy(f1).cuda()), fixed)
 
 
+@pytest.mark.parametrize("n", [1, 2, 767, 768, 769, 1537, 2311])
+def test_persistent_kernel_at_its_own_grid_equals_the_generic_kernel(monkeypatch, n):
+    """Env counts around the persistent grid (768 workgroups on an MI355X: fewer frames than workgroups, exactly one each, one
+    more, two rounds and a bit, three rounds and a bit): the planes equal the one-workgroup-per-frame kernel's, which the
+    other tests pin against the oracle."""
+    from gym_amd.atari import AtariPreprocessor
+    g = torch.Generator(device="cuda").manual_seed(n)
+    frames = torch.randint(0, 256, (n, 2, H, W, 3), dtype=torch.uint8, device="cuda", generator=g)
+    pp = AtariPreprocessor(n)
+    fixed = pp.preprocess(frames).clone()
+    pp.reset(frames); pp.step(frames)
+    ring_fixed = pp.stacked_nhwc().clone()
+    monkeypatch.setenv("GYMHIP_ATARI_GENERIC", "1")
+    assert torch.equal(pp.preprocess(frames), fixed)
+    pp.reset(frames); pp.step(frames)
+    assert torch.equal(pp.stacked_nhwc(), ring_fixed)
+    assert torch.equal(ring_fixed[..., -1], fixed) and torch.equal(ring_fixed[..., -2], fixed) and (ring_fixed[..., :2] == 0).all()
+
+
 def test_a_recorded_ring_revolution_replays_like_eager_steps():
     """HIP graph capture of the image path.  The ring's `head` is HOST state (gymhip.h), so a recording of one step would
     replay into the same slot; a recording of n_stack consecutive steps — a whole revolution, each with its NCHW view — leaves
